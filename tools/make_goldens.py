@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+    python tools/make_goldens.py [--ref /root/reference] [--out tests/golden]
+
+The reference (LaurenYTaylor/jsrl-CORL, algorithms/finetune/iql.py) is imported
+from where it lies; nothing of it is copied.  Its host-only third-party imports
+that are not installed here (gym, gymnasium, d4rl, pyrallis, wandb) are replaced
+by empty stub modules — the classes on the IQL step path use torch+numpy only
+(SURVEY.md Appendix B).  Inputs come from jsrl-corl_amd/synth.py (numpy PCG64),
+so a fixture holds (seed, dims, hyper-parameters) + the reference's OUTPUTS.
+
+Large tensors are stored sub-sampled (every `stride`-th element of the
+flattened tensor); tests apply the same sub-sampling to what they compare.
+This script never runs on the GPU box (the reference does not travel).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _load_synth():
+    spec = importlib.util.spec_from_file_location("iqlhip_synth", os.path.join(ROOT, "jsrl-corl_amd", "synth.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+synth = _load_synth()
+
+
+def import_reference(ref_root: str):
+    """Import the reference's finetune/iql.py with stubbed host-only deps."""
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Env:  # annotation target only
+        pass
+
+    for pkg in ("gym", "gymnasium"):
+        wr = stub(pkg + ".wrappers")
+        sp = stub(pkg + ".spaces", Discrete=type("Discrete", (), {}))
+        stub(pkg, Env=_Env, wrappers=wr, spaces=sp, register_envs=lambda *a, **k: None)
+    stub("d4rl")
+    stub("wandb")
+    stub("pyrallis", wrap=lambda *a, **k: (lambda fn: fn), dump=lambda *a, **k: None,
+         parse=lambda *a, **k: None)
+    sys.path.insert(0, os.path.join(ref_root, "algorithms", "finetune"))
+    import iql as ref_iql  # noqa: E402  (the reference module)
+    return ref_iql
+
+
+# ----------------------------------------------------------------------------
+def sub(arr: np.ndarray, stride: int) -> np.ndarray:
+    a = np.asarray(arr)
+    if a.size > 4096:
+        return a.ravel()[::stride].copy()
+    return a.copy()
+
+
+NET_KEYS = {  # our tensor names -> reference state_dict keys
+    "vf": {"w0": "v.net.0.weight", "b0": "v.net.0.bias", "w1": "v.net.2.weight", "b1": "v.net.2.bias",
+           "w2": "v.net.4.weight", "b2": "v.net.4.bias"},
+    "q1": {"w0": "q1.net.0.weight", "b0": "q1.net.0.bias", "w1": "q1.net.2.weight", "b1": "q1.net.2.bias",
+           "w2": "q1.net.4.weight", "b2": "q1.net.4.bias"},
+    "q2": {"w0": "q2.net.0.weight", "b0": "q2.net.0.bias", "w1": "q2.net.2.weight", "b1": "q2.net.2.bias",
+           "w2": "q2.net.4.weight", "b2": "q2.net.4.bias"},
+    "pi": {"w0": "net.net.0.weight", "b0": "net.net.0.bias", "w1": "net.net.2.weight", "b1": "net.net.2.bias",
+           "w2": "net.net.4.weight", "b2": "net.net.4.bias", "log_std": "log_std"},
+}
+
+
+def build_trainer(ref, S, A, params, gaussian, hyper, lrs, max_steps):
+    qf = ref.TwinQ(S, A)
+    vf = ref.ValueFunction(S)
+    actor = (ref.GaussianPolicy if gaussian else ref.DeterministicPolicy)(S, A, 1.0)
+    mods = {"vf": vf, "q1": qf, "q2": qf, "pi": actor}
+    with torch.no_grad():
+        for net, keys in NET_KEYS.items():
+            sd = dict(mods[net].named_parameters())
+            for ours, theirs in keys.items():
+                if ours in params[net]:
+                    sd[theirs].copy_(torch.from_numpy(params[net][ours]))
+    v_opt = torch.optim.Adam(vf.parameters(), lr=lrs["v"])
+    q_opt = torch.optim.Adam(qf.parameters(), lr=lrs["q"])
+    a_opt = torch.optim.Adam(actor.parameters(), lr=lrs["pi"])
+    tr = ref.ImplicitQLearning(
+        max_action=1.0, actor=actor, actor_optimizer=a_opt, q_network=qf, q_optimizer=q_opt,
+        v_network=vf, v_optimizer=v_opt, iql_tau=hyper["iql_tau"], beta=hyper["beta"],
+        max_steps=max_steps, discount=hyper["discount"], tau=hyper["tau"], device="cpu")
+    with torch.no_grad():  # distinct target weights
+        tsd = dict(tr.q_target.named_parameters())
+        for net, tnet in (("q1", "qt1"), ("q2", "qt2")):
+            for ours, theirs in NET_KEYS[net].items():
+                tsd[theirs].copy_(torch.from_numpy(params[tnet][ours]))
+    return tr
+
+
+def grab(tr, stride, gaussian):
+    """Current params / grads / Adam moments / target as sub-sampled numpy."""
+    out = {}
+    mods = {"vf": (tr.vf, tr.v_optimizer), "q1": (tr.qf, tr.q_optimizer), "q2": (tr.qf, tr.q_optimizer),
+            "pi": (tr.actor, tr.actor_optimizer)}
+    for net, keys in NET_KEYS.items():
+        mod, opt = mods[net]
+        named = dict(mod.named_parameters())
+        for ours, theirs in keys.items():
+            if ours == "log_std" and not gaussian:
+                continue
+            p = named[theirs]
+            out[f"param.{net}.{ours}"] = sub(p.detach().numpy(), stride)
+            if p.grad is not None:
+                out[f"grad.{net}.{ours}"] = sub(p.grad.numpy(), stride)
+            st = opt.state.get(p, None)
+            if st:
+                out[f"m.{net}.{ours}"] = sub(st["exp_avg"].numpy(), stride)
+                out[f"v.{net}.{ours}"] = sub(st["exp_avg_sq"].numpy(), stride)
+    tnamed = dict(tr.q_target.named_parameters())
+    for net, tnet in (("q1", "qt1"), ("q2", "qt2")):
+        for ours, theirs in NET_KEYS[net].items():
+            out[f"param.{tnet}.{ours}"] = sub(tnamed[theirs].detach().numpy(), stride)
+    return out
+
+
+def to_batch(d, idx=None):
+    if idx is None:
+        idx = np.arange(d["observations"].shape[0])
+    return [torch.from_numpy(d["observations"][idx]), torch.from_numpy(d["actions"][idx]),
+            torch.from_numpy(d["rewards"][idx][:, None]), torch.from_numpy(d["next_observations"][idx]),
+            torch.from_numpy(d["terminals"][idx][:, None])]
+
+
+def ref_intermediates(tr, batch):
+    """next_v / target_q / v / adv from PRE-step params, using the reference modules."""
+    with torch.no_grad():
+        s, a, r, ns, d = batch
+        nv = tr.vf(ns)
+        tq = tr.q_target(s, a)
+        v = tr.vf(s)
+        q1, q2 = tr.qf.both(s, a)
+        out = {"next_v": nv.numpy(), "target_q": tq.numpy(), "v": v.numpy(), "adv": (tq - v).numpy(),
+               "q1": q1.numpy(), "q2": q2.numpy()}
+        pol = tr.actor(s)
+        out["mu"] = (pol.mean if hasattr(pol, "mean") and not torch.is_tensor(pol) else pol).numpy()
+    return out
+
+
+def single_step_case(ref, name, S, A, gaussian, beta, iql_tau, B, seed, stride, outdir, edge=False):
+    hyper = {"iql_tau": iql_tau, "beta": beta, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    params = synth.synth_params(S, A, seed=seed, gaussian=gaussian)
+    data = synth.synth_transitions(B, S, A, seed=1000 + seed)
+    if edge:
+        # G7: exp(beta*adv) overflow on some rows, log_std outside / on the clamp
+        # bounds, terminal rows, duplicated rows.
+        params["qt1"]["b2"] = params["qt1"]["b2"] + np.float32(60.0)
+        params["qt2"]["b2"] = params["qt2"]["b2"] + np.float32(60.0)
+        if gaussian:
+            ls = np.zeros(A, dtype=np.float32)
+            ls[:6] = np.array([3.0, -25.0, 0.5, 2.0, -20.0, -1.0], dtype=np.float32)[: min(6, A)]
+            params["pi"]["log_std"] = ls
+        data["terminals"][: B // 4] = 1.0
+        for k in data:
+            data[k][B // 2: B // 2 + 16] = data[k][:16]
+        # half of the rows get a very negative advantage instead (w -> 0)
+        data["observations"][B // 2 + 16:] *= np.float32(1.0)
+    tr = build_trainer(ref, S, A, params, gaussian, hyper, lrs, max_steps=1000)
+    batch = to_batch(data)
+    inter = ref_intermediates(tr, batch)
+    log = tr.train(batch)
+    out = grab(tr, stride, gaussian)
+    out.update({f"inter.{k}": v for k, v in inter.items()})
+    out["losses"] = np.array([log["value_loss"], log["q_loss"], log["actor_loss"]], dtype=np.float64)
+    out["lr_after"] = np.array([tr.actor_optimizer.param_groups[0]["lr"]], dtype=np.float64)
+    meta = {"kind": "single_step", "S": S, "A": A, "gaussian": gaussian, "B": B, "seed": seed,
+            "stride": stride, "hyper": hyper, "lrs": lrs, "max_steps": 1000, "edge": edge}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez(os.path.join(outdir, name + ".npz"), **out)
+    print(f"{name}: losses={out['losses']}")
+
+
+def freerun_case(ref, name, S, A, gaussian, n_steps, B, N, seed, stride, outdir, T=1000):
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    params = synth.synth_params(S, A, seed=seed, gaussian=gaussian)
+    data = synth.synth_transitions(N, S, A, seed=2000 + seed)
+    tr = build_trainer(ref, S, A, params, gaussian, hyper, lrs, max_steps=T)
+    buf = ref.ReplayBuffer(S, A, N, "cpu")
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    np.random.seed(seed)
+    losses, lrs_used, idxs = [], [], []
+    for _ in range(n_steps):
+        st = np.random.get_state()
+        batch = buf.sample(B)
+        np.random.set_state(st)
+        idxs.append(np.random.randint(0, N, size=B))  # same draw the buffer just made
+        lrs_used.append(tr.actor_optimizer.param_groups[0]["lr"])
+        log = tr.train(batch)
+        losses.append([log["value_loss"], log["q_loss"], log["actor_loss"]])
+    out = grab(tr, stride, gaussian)
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["actor_lr_used"] = np.array(lrs_used, dtype=np.float64)
+    out["indices"] = np.array(idxs, dtype=np.int64)
+    out["total_it"] = np.array([tr.total_it])
+    meta = {"kind": "free_run", "S": S, "A": A, "gaussian": gaussian, "B": B, "N": N, "seed": seed,
+            "stride": stride, "hyper": hyper, "lrs": lrs, "max_steps": T, "n_steps": n_steps}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez(os.path.join(outdir, name + ".npz"), **out)
+    print(f"{name}: last losses={losses[-1]}")
+
+
+def gather_case(ref, outdir):
+    S, A, N, B = 17, 6, 4096, 256
+    data = synth.synth_transitions(N, S, A, seed=3)
+    import contextlib
+    import io
+    buf = ref.ReplayBuffer(S, A, N + 100, "cpu")
+    with contextlib.redirect_stdout(io.StringIO()):
+        buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    np.random.seed(123)
+    s, a, r, ns, d = buf.sample(B)
+    np.random.seed(123)
+    idx = np.random.randint(0, N, size=B)
+    np.savez(os.path.join(outdir, "g3_gather.npz"), indices=idx, s=s.numpy(), a=a.numpy(), r=r.numpy(),
+             ns=ns.numpy(), d=d.numpy(),
+             meta=np.array(json.dumps({"S": S, "A": A, "N": N, "B": B, "data_seed": 3, "np_seed": 123,
+                                       "capacity": N + 100, "size": buf._size, "pointer": buf._pointer})))
+    print("g3_gather ok", r.shape, d.shape)
+
+
+def ring_case(ref, outdir):
+    S, A, cap = 3, 2, 8
+    data = synth.synth_transitions(5, S, A, seed=4)
+    extra = synth.synth_transitions(7, S, A, seed=5)
+    import contextlib
+    import io
+    buf = ref.ReplayBuffer(S, A, cap, "cpu")
+    with contextlib.redirect_stdout(io.StringIO()):
+        buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    trace = [(buf._pointer, buf._size)]
+    for i in range(7):
+        buf.add_transition(extra["observations"][i], extra["actions"][i], float(extra["rewards"][i]),
+                           extra["next_observations"][i], bool(extra["terminals"][i] > 0.5 or i == 2))
+        trace.append((buf._pointer, buf._size))
+    # error behaviour of load_d4rl_dataset
+    errs = {}
+    try:
+        buf.load_d4rl_dataset(data)
+    except ValueError as e:
+        errs["nonempty"] = str(e)
+    try:
+        ref.ReplayBuffer(S, A, 3, "cpu").load_d4rl_dataset(data)
+    except ValueError as e:
+        errs["too_small"] = str(e)
+    np.savez(os.path.join(outdir, "g4_ring.npz"), states=buf._states.numpy(), actions=buf._actions.numpy(),
+             rewards=buf._rewards.numpy(), next_states=buf._next_states.numpy(), dones=buf._dones.numpy(),
+             trace=np.array(trace, dtype=np.int64),
+             meta=np.array(json.dumps({"S": S, "A": A, "capacity": cap, "load_seed": 4, "extra_seed": 5,
+                                       "errors": errs})))
+    print("g4_ring ok", trace[-1], errs)
+
+
+def lr_case(ref, outdir):
+    T = 1000
+    S, A = 3, 2
+    params = synth.synth_params(S, A, seed=0)
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    tr = build_trainer(ref, S, A, params, True, hyper, {"v": 3e-4, "q": 3e-4, "pi": 3e-4}, max_steps=T)
+    lrs = [tr.actor_optimizer.param_groups[0]["lr"]]
+    tr.actor_optimizer._opt_called = True  # silence the scheduler-order warning
+    for _ in range(3 * T // 2):
+        tr.actor_lr_schedule.step()
+        lrs.append(tr.actor_optimizer.param_groups[0]["lr"])
+    tr2 = build_trainer(ref, S, A, params, True, hyper, {"v": 3e-4, "q": 3e-4, "pi": 3e-4}, max_steps=None)
+    np.savez(os.path.join(outdir, "g5_lr.npz"), lrs=np.array(lrs, dtype=np.float64),
+             meta=np.array(json.dumps({"T": T, "base_lr": 3e-4, "no_schedule_is_none": tr2.actor_lr_schedule is None,
+                                       "sched_state_keys": sorted(tr.actor_lr_schedule.state_dict().keys())})))
+    print("g5_lr ok", lrs[0], lrs[T], lrs[-1])
+
+
+def statedict_case(ref, outdir):
+    S, A = 17, 6
+    params = synth.synth_params(S, A, seed=6)
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    tr = build_trainer(ref, S, A, params, True, hyper, {"v": 3e-4, "q": 3e-4, "pi": 3e-4}, max_steps=1000)
+    data = synth.synth_transitions(64, S, A, seed=61)
+    tr.train(to_batch(data))
+    sd = tr.state_dict()
+    desc = {}
+    for k in ("qf", "vf", "actor"):
+        desc[k] = {kk: list(vv.shape) for kk, vv in sd[k].items()}
+    for k in ("q_optimizer", "v_optimizer", "actor_optimizer"):
+        o = sd[k]
+        desc[k] = {"state_keys": sorted(str(x) for x in o["state"].keys()),
+                   "entry_keys": sorted(o["state"][0].keys()),
+                   "step0": float(o["state"][0]["step"]),
+                   "param_group_keys": sorted(o["param_groups"][0].keys()),
+                   "params": o["param_groups"][0]["params"]}
+    desc["actor_lr_schedule"] = {k: (v if isinstance(v, (int, float, bool, str)) else str(v))
+                                 for k, v in sd["actor_lr_schedule"].items()}
+    desc["total_it"] = sd["total_it"]
+    desc["top_keys"] = list(sd.keys())
+    # after load_state_dict the target equals qf (reference quirk, Appendix A)
+    tr2 = build_trainer(ref, S, A, synth.synth_params(S, A, seed=7), True, hyper,
+                        {"v": 3e-4, "q": 3e-4, "pi": 3e-4}, max_steps=1000)
+    tr2.load_state_dict(sd)
+    same = all(torch.equal(a, b) for a, b in zip(tr2.q_target.parameters(), tr2.qf.parameters()))
+    desc["target_equals_qf_after_load"] = bool(same)
+    desc["target_requires_grad_after_load"] = bool(next(tr2.q_target.parameters()).requires_grad)
+    log = tr2.train(to_batch(synth.synth_transitions(64, S, A, seed=62)))
+    np.savez(os.path.join(outdir, "g6_statedict.npz"),
+             losses_after_load=np.array([log["value_loss"], log["q_loss"], log["actor_loss"]], dtype=np.float64),
+             meta=np.array(json.dumps(desc)))
+    print("g6_statedict ok", desc["top_keys"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(1)
+    ref = import_reference(args.ref)
+
+    cid = 0
+    for (S, A) in ((17, 6), (29, 8), (39, 28)):
+        for gaussian in (True, False):
+            for (beta, tq) in ((3.0, 0.7), (10.0, 0.9)):
+                name = f"g1_S{S}A{A}_{'gauss' if gaussian else 'det'}_b{int(beta)}"
+                single_step_case(ref, name, S, A, gaussian, beta, tq, 256, cid, 7 if cid == 0 else 13, args.out)
+                cid += 1
+    single_step_case(ref, "g7_edge_gauss", 17, 6, True, 3.0, 0.7, 256, 50, 13, args.out, edge=True)
+    single_step_case(ref, "g7_edge_det", 17, 6, False, 10.0, 0.9, 256, 51, 13, args.out, edge=True)
+    single_step_case(ref, "g1_ragged_B100", 17, 6, True, 3.0, 0.7, 100, 52, 13, args.out)
+    single_step_case(ref, "g8_dp_B2048", 17, 6, True, 3.0, 0.7, 2048, 60, 13, args.out)
+    freerun_case(ref, "g2_freerun_S17A6", 17, 6, True, 10, 256, 4096, 70, 13, args.out)
+    freerun_case(ref, "g2_freerun_S29A8_det", 29, 8, False, 10, 256, 4096, 71, 13, args.out)
+    gather_case(ref, args.out)
+    ring_case(ref, args.out)
+    lr_case(ref, args.out)
+    statedict_case(ref, args.out)
+
+
+if __name__ == "__main__":
+    main()
