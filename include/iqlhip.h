@@ -1,0 +1,185 @@
+/*
+ * iqlhip.h — C ABI of libiqlhip.so: the MI355X (gfx950) implementation of the
+ * IQL gradient step of LaurenYTaylor/jsrl-CORL.
+ *
+ * The reference has no FFI: its boundary is the Python class surface of
+ * algorithms/finetune/iql.py (ReplayBuffer :122-197, ImplicitQLearning :445-606).
+ * Each entry point below names the reference method whose device work it
+ * replaces; jsrl-corl_amd/iql.py is the Python shim that keeps those classes'
+ * signatures and calls these symbols through ctypes.  INTEGRATION.md shows the
+ * binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; every pointer named *_dev is device memory owned by the
+ *    CALLER (torch tensors in the shim); the library never frees it.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *    all calls are asynchronous on it unless stated otherwise.
+ *  - return 0 on success, negative IQLHIP_E* otherwise; iqlhip_last_error() gives
+ *    the message (thread-local).  No C++ exception crosses the boundary.
+ *  - a context is not thread-safe; one context per (process, GPU).
+ *  - all arithmetic is fp32 ("f32" in bench.py's dtype); GEMMs run on
+ *    v_mfma_f32_16x16x4_f32 (exact fp32 fma chains).
+ */
+#ifndef IQLHIP_H
+#define IQLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IQLHIP_VERSION 100          /* 0.1.0 */
+#define IQLHIP_HIDDEN 256           /* hidden width the kernels are tiled for (reference default, iql.py:352) */
+#define IQLHIP_MAX_INPUT 128        /* max state_dim + action_dim */
+#define IQLHIP_MAX_ACTION 32        /* max action_dim */
+
+enum {
+  IQLHIP_OK = 0,
+  IQLHIP_EINVAL = -1,    /* bad argument (maps to ValueError in the shim) */
+  IQLHIP_EHIP = -2,      /* a HIP runtime call failed (RuntimeError) */
+  IQLHIP_ENOTBOUND = -3, /* step before iqlhip_bind */
+  IQLHIP_EUNSUPPORTED = -4 /* dims the kernels are not built for (NotImplementedError) */
+};
+
+enum { IQLHIP_NET_V = 0, IQLHIP_NET_Q1 = 1, IQLHIP_NET_Q2 = 2, IQLHIP_NET_PI = 3 };
+enum { IQLHIP_POLICY_GAUSSIAN = 0, IQLHIP_POLICY_DETERMINISTIC = 1 };
+
+/* ---- dimensions -------------------------------------------------------- */
+typedef struct {
+  int32_t state_dim;     /* S */
+  int32_t action_dim;    /* A */
+  int32_t hidden_dim;    /* must be IQLHIP_HIDDEN */
+  int32_t n_hidden;      /* must be 2 (MLP [in,256,256,out], iql.py:351-356) */
+  int32_t policy;        /* IQLHIP_POLICY_* (GaussianPolicy :347 / DeterministicPolicy :382) */
+  int32_t max_batch;     /* largest batch a step will be called with */
+} iqlhip_dims;
+
+/* Offsets (in floats) of one MLP's tensors inside the flat parameter arena.
+ * Weights keep torch.nn.Linear's [out,in] row-major layout. */
+typedef struct {
+  int64_t seg_begin, seg_end;  /* [begin,end) of this net's segment, multiples of 64 */
+  int64_t w0, b0, w1, b1, w2, b2, log_std;  /* log_std = -1 when absent */
+  int32_t k_in;    /* input width of layer 0: S (V, pi) or S+A (Q) */
+  int32_t d_out;   /* 1 (V, Q) or A (pi) */
+} iqlhip_net_layout;
+
+typedef struct {
+  iqlhip_net_layout net[4];   /* IQLHIP_NET_* order: V, Q1, Q2, PI */
+  int64_t n_params;           /* floats in the trainable arena (= Adam exp_avg / exp_avg_sq arenas) */
+  int64_t n_target;           /* floats in the target arena: copy of the [Q1,Q2] segments */
+  int64_t target_src;         /* arena offset of Q1's segment: target[i] mirrors params[target_src+i] */
+} iqlhip_layout;
+
+/* Pure host function (no GPU needed).  Replaces nothing in the reference: the
+ * reference keeps one tensor per nn.Parameter; the shim re-homes them as views
+ * into ONE arena laid out by this function so a step touches three flat buffers. */
+int iqlhip_arena_layout(const iqlhip_dims* dims, iqlhip_layout* out);
+
+/* ---- hyper-parameters and per-step scalars ------------------------------ */
+typedef struct {
+  float iql_tau;    /* expectile, ImplicitQLearning(iql_tau)  iql.py:454,490 */
+  float beta;       /* inverse temperature                    iql.py:455,524 */
+  float discount;   /* gamma                                  iql.py:457,506 */
+  float tau;        /* Polyak rate, cast of the python float  iql.py:458,515 */
+  float one_minus_tau; /* (float)(1.0 - tau) formed in float64 first (iql.py:74) */
+  float exp_adv_max;   /* EXP_ADV_MAX = 100                   iql.py:26 */
+  float log_std_min, log_std_max; /* -20, 2                  iql.py:27-28 */
+} iqlhip_hyper;
+
+/* Host-computed (float64 -> float32) scalars of torch.optim.Adam's
+ * _single_tensor_adam for THIS step; group order V, Q, PI. */
+typedef struct {
+  float step_size[3];   /* lr_g / (1 - beta1^t_g) */
+  float bc2_sqrt[3];    /* sqrt(1 - beta2^t_g) */
+  float beta2;          /* (float)beta2 */
+  float one_minus_beta1;/* (float)(1 - beta1) : lerp weight */
+  float one_minus_beta2;/* (float)(1 - beta2) */
+  float eps;
+  float grad_scale;     /* 1 for single GPU; 1/world after a summed all-reduce */
+  float inv_batch;      /* 1 / (rows the batch means divide by): 1/B, or 1/(B*world) under DP */
+} iqlhip_step_scalars;
+
+/* One batch, either gathered already (idx_dev == NULL; five separate row-major
+ * tensors as returned by ReplayBuffer.sample, iql.py:171-178) or addressed
+ * through int64 row indices into buffer storage (ld_* = row strides in floats). */
+typedef struct {
+  const float* s_dev; const float* a_dev; const float* r_dev; const float* ns_dev; const float* d_dev;
+  int64_t ld_s, ld_a, ld_r, ld_ns, ld_d;
+  const int64_t* idx_dev;
+  int32_t rows;
+} iqlhip_batch;
+
+typedef struct iqlhip_ctx iqlhip_ctx;
+
+/* ---- life cycle --------------------------------------------------------- */
+int iqlhip_version(void);
+const char* iqlhip_last_error(void);
+
+/* ImplicitQLearning.__init__ (iql.py:446-480): allocates library-owned scratch
+ * (activations, gradient slabs, loss words) on `device`. */
+int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper, int device, iqlhip_ctx** out);
+int iqlhip_destroy(iqlhip_ctx* ctx);
+int iqlhip_set_hyper(iqlhip_ctx* ctx, const iqlhip_hyper* hyper);
+
+/* Bind the caller-owned arenas: params (n_params), target (n_target; the
+ * deepcopy q_target of iql.py:461), Adam exp_avg / exp_avg_sq (n_params each). */
+int iqlhip_bind(iqlhip_ctx* ctx, float* params_dev, float* target_dev, float* exp_avg_dev, float* exp_avg_sq_dev);
+
+/* ---- the step ----------------------------------------------------------- */
+/* ImplicitQLearning.train(batch) (iql.py:542-563) minus the host syncs: forward
+ * of V(s'), V(s), Qt1, Qt2, Q1, Q2, pi; the three losses; backward; Adam on the
+ * three groups; Polyak.  Losses land in device words read by iqlhip_read_losses. */
+int iqlhip_step(iqlhip_ctx* ctx, const iqlhip_batch* batch, const iqlhip_step_scalars* sc, void* stream);
+
+/* Data-parallel split of the same step: forward+backward, then the
+ * flat gradient (n_params floats + 4 tail words: 3 loss sums and a spare) is
+ * written to grads_dev for the caller's all-reduce, then the update consumes it. */
+int iqlhip_forward_backward(iqlhip_ctx* ctx, const iqlhip_batch* batch, const iqlhip_step_scalars* sc,
+                            float* grads_dev, void* stream);
+int iqlhip_apply_update(iqlhip_ctx* ctx, const float* grads_dev, const iqlhip_step_scalars* sc, void* stream);
+int64_t iqlhip_grad_words(const iqlhip_ctx* ctx);   /* n_params + 4 */
+
+/* K consecutive steps captured in one hipGraph: indices are drawn on the device
+ * (Philox4x32-10, uniform with replacement over [0,size) like np.random.randint
+ * at iql.py:172), per-step scalars come from `sc` (host array of n_steps).
+ * Loss of every step is kept in a device ring read by iqlhip_read_loss_ring.
+ * Replaces the offline loop body sample()->train() (algorithms/offline/iql.py:631-635). */
+int iqlhip_train_steps(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int64_t size, int32_t batch_rows,
+                       const iqlhip_step_scalars* sc, int32_t n_steps, uint64_t seed, uint64_t stream_offset,
+                       void* stream);
+
+/* The three .item() calls of iql.py:491,509,535: synchronises `stream`. out = {value,q,actor}. */
+int iqlhip_read_losses(iqlhip_ctx* ctx, float out[3], void* stream);
+int iqlhip_read_loss_ring(iqlhip_ctx* ctx, float* out, int32_t n_steps, void* stream);
+
+/* ---- replay buffer storage (packed rows [s | a | s' | r | d | pad]) ------ */
+/* Row stride in floats for given dims (multiple of 4 floats = 16 B). */
+int64_t iqlhip_row_stride(int32_t state_dim, int32_t action_dim);
+/* ReplayBuffer.load_d4rl_dataset / add_transition (iql.py:153-169,180-196): write n
+ * rows starting at row0 from five contiguous device arrays. */
+int iqlhip_rows_write(float* rows_dev, int64_t ld, int32_t state_dim, int32_t action_dim, int64_t row0, int64_t n,
+                      const float* s_dev, const float* a_dev, const float* r_dev, const float* ns_dev,
+                      const float* d_dev, void* stream);
+/* ReplayBuffer.sample's five advanced-index gathers (iql.py:173-177) in one launch. */
+int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t state_dim, int32_t action_dim,
+                       const int64_t* idx_dev, int64_t n, float* s_dev, float* a_dev, float* r_dev, float* ns_dev,
+                       float* d_dev, void* stream);
+/* Device-side index draw used by iqlhip_train_steps, exposed for tests. */
+int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---- introspection (tests, profiling) ----------------------------------- */
+/* Copy a named library-owned scratch array to host (synchronous).  Names:
+ * "h0","h1" (activations [4][max_batch][256]), "heads" (partial head sums),
+ * "grads" (flat summed gradient, n_params), "loss_parts". */
+int iqlhip_debug_read(iqlhip_ctx* ctx, const char* name, float* host_out, int64_t max_floats, int64_t* n_out,
+                      void* stream);
+/* Average device time (microseconds) of the kernels of the last iqlhip_step /
+ * train_steps call measured with hipEvents on `stream`; 0 when timing is off. */
+int iqlhip_set_timing(iqlhip_ctx* ctx, int enabled);
+int iqlhip_get_timing(iqlhip_ctx* ctx, float out_us[4]); /* fwd, bwd, update, total */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IQLHIP_H */

@@ -1,0 +1,523 @@
+// iqlhip.hip — C ABI (include/iqlhip.h) of the MI355X IQL step.  Host side:
+// arena layout, scratch management, launches, hipGraph capture of K-step chunks.
+#include "iqlhip_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(IQLHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct GraphKey {
+  const float* rows = nullptr;
+  int64_t ld = 0;
+  int32_t B = 0, K = 0;
+  float* params = nullptr;
+  bool operator==(const GraphKey& o) const {
+    return rows == o.rows && ld == o.ld && B == o.B && K == o.K && params == o.params;
+  }
+};
+
+struct iqlhip_ctx {
+  iqlhip_dims dims;
+  iqlhip_hyper hyper;
+  iqlhip_layout L;
+  int device = 0;
+  // bound (caller-owned)
+  float *params = nullptr, *target = nullptr, *m = nullptr, *v = nullptr;
+  // scratch (library-owned)
+  DevScratch sc{};
+  float* flat_tmp = nullptr;          // n_params + 4 (debug "grads")
+  float* loss_ring = nullptr;         // [ring_cap][4]
+  int ring_cap = 0;
+  long long* idx_chunk = nullptr;     // [K_max * max_batch]
+  iqlhip_step_scalars* sched = nullptr;  // [K_max]
+  unsigned long long* hdr = nullptr;  // {size, seed, offset}
+  int k_max = 0;
+  int n_chunk_max = 0, n_rt_max = 0;
+  size_t lds_fwd = 0, lds_bwd = 0;
+  // graph cache
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  GraphKey gkey;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;         // 4 per recorded step
+  int ev_used = 0;
+  float t_acc[4] = {0, 0, 0, 0};
+  int t_n = 0;
+};
+
+extern "C" int iqlhip_version(void) { return IQLHIP_VERSION; }
+extern "C" const char* iqlhip_last_error(void) { return g_err.c_str(); }
+
+static int check_dims(const iqlhip_dims* d) {
+  if (!d) return fail(IQLHIP_EINVAL, "dims is NULL");
+  if (d->state_dim < 1 || d->action_dim < 1) return fail(IQLHIP_EINVAL, "state_dim/action_dim must be >= 1");
+  if (d->hidden_dim != IQLHIP_HIDDEN || d->n_hidden != 2)
+    return fail(IQLHIP_EUNSUPPORTED, "kernels are built for hidden_dim=%d, n_hidden=2 (got %d, %d)", IQLHIP_HIDDEN,
+                d->hidden_dim, d->n_hidden);
+  if (d->state_dim + d->action_dim > IQLHIP_MAX_INPUT)
+    return fail(IQLHIP_EUNSUPPORTED, "state_dim + action_dim > %d", IQLHIP_MAX_INPUT);
+  if (d->action_dim > IQLHIP_MAX_ACTION) return fail(IQLHIP_EUNSUPPORTED, "action_dim > %d", IQLHIP_MAX_ACTION);
+  if (d->policy != IQLHIP_POLICY_GAUSSIAN && d->policy != IQLHIP_POLICY_DETERMINISTIC)
+    return fail(IQLHIP_EINVAL, "unknown policy kind %d", d->policy);
+  if (d->max_batch < 1 || d->max_batch > 16384) return fail(IQLHIP_EINVAL, "max_batch must be in [1,16384]");
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_arena_layout(const iqlhip_dims* d, iqlhip_layout* out) {
+  int rc = check_dims(d);
+  if (rc) return rc;
+  if (!out) return fail(IQLHIP_EINVAL, "out is NULL");
+  const int S = d->state_dim, A = d->action_dim, Hd = IQLHIP_HIDDEN;
+  int64_t off = 0;
+  for (int n = 0; n < 4; ++n) {
+    iqlhip_net_layout& nl = out->net[n];
+    nl.k_in = (n == IQLHIP_NET_Q1 || n == IQLHIP_NET_Q2) ? S + A : S;
+    nl.d_out = (n == IQLHIP_NET_PI) ? A : 1;
+    nl.seg_begin = off;
+    nl.w1 = off; off += (int64_t)Hd * Hd;
+    nl.w0 = off; off += (int64_t)Hd * nl.k_in;
+    nl.b0 = off; off += Hd;
+    nl.b1 = off; off += Hd;
+    nl.w2 = off; off += (int64_t)nl.d_out * Hd;
+    nl.b2 = off; off += up(nl.d_out, 4);
+    if (n == IQLHIP_NET_PI && d->policy == IQLHIP_POLICY_GAUSSIAN) { nl.log_std = off; off += up(A, 4); }
+    else nl.log_std = -1;
+    off = up(off, 64);
+    nl.seg_end = off;
+  }
+  out->n_params = off;
+  out->target_src = out->net[IQLHIP_NET_Q1].seg_begin;
+  out->n_target = out->net[IQLHIP_NET_Q2].seg_end - out->net[IQLHIP_NET_Q1].seg_begin;
+  return IQLHIP_OK;
+}
+
+extern "C" int64_t iqlhip_row_stride(int32_t S, int32_t A) { return up(2 * (int64_t)S + A + 2, 4); }
+
+static int xld_host(int k0) { int k0p = (k0 + 3) & ~3; return ((k0p + 29) / 32) * 32 + 2; }
+
+extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper, int device, iqlhip_ctx** out) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  if (!hyper || !out) return fail(IQLHIP_EINVAL, "hyper/out is NULL");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(IQLHIP_EHIP, "device %d not available (%d visible)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  iqlhip_ctx* c = new iqlhip_ctx();
+  c->dims = *dims;
+  c->hyper = *hyper;
+  c->device = device;
+  iqlhip_arena_layout(dims, &c->L);
+  const int MB = dims->max_batch, A = dims->action_dim;
+  c->n_chunk_max = (MB + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  c->n_rt_max = (MB + RT_ROWS - 1) / RT_ROWS;
+  c->sc.max_batch = MB;
+  auto dalloc = [&](float** p, size_t nfloat) -> hipError_t {
+    hipError_t e = hipMalloc((void**)p, nfloat * sizeof(float));
+    if (e != hipSuccess) return e;
+    return hipMemset(*p, 0, nfloat * sizeof(float));
+  };
+  HIPCHK(dalloc(&c->sc.h0, (size_t)4 * MB * HID));
+  HIPCHK(dalloc(&c->sc.h1, (size_t)4 * MB * HID));
+  HIPCHK(dalloc(&c->sc.heads, (size_t)6 * NSPLIT * MB + (size_t)NSPLIT * MB * A));
+  HIPCHK(dalloc(&c->sc.slab_a, (size_t)c->n_chunk_max * c->L.n_params));
+  size_t sb = 0;
+  for (int n = 0; n < 4; ++n) {
+    c->sc.slab_b_off[n] = (long long)sb;
+    sb += (size_t)c->n_rt_max * ((size_t)HID * c->L.net[n].k_in + HID);
+  }
+  HIPCHK(dalloc(&c->sc.slab_b, sb));
+  HIPCHK(dalloc(&c->sc.loss_parts, 4 * 64));
+  HIPCHK(dalloc(&c->sc.losses, 4));
+  HIPCHK(dalloc(&c->flat_tmp, (size_t)c->L.n_params + 4));
+  c->k_max = 1024;
+  c->ring_cap = c->k_max;
+  HIPCHK(dalloc(&c->loss_ring, (size_t)c->ring_cap * 4));
+  HIPCHK(hipMalloc((void**)&c->idx_chunk, (size_t)c->k_max * MB * sizeof(long long)));
+  HIPCHK(hipMalloc((void**)&c->sched, (size_t)c->k_max * sizeof(iqlhip_step_scalars)));
+  HIPCHK(hipMalloc((void**)&c->hdr, 4 * sizeof(unsigned long long)));
+  HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+  // LDS sizes
+  const int kq = dims->state_dim + dims->action_dim;
+  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * xld_host(kq)) * sizeof(float);
+  const int dyld = ((A + 15) & ~15) + 1;
+  const size_t lds_a = (size_t)(4 * 32 * T64_LD + 2 * CHUNK_ROWS * dyld + 32 * 32 + 64) * sizeof(float);
+  const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 33 +
+                                RT_ROWS * xld_host(kq)) * sizeof(float);
+  c->lds_bwd = std::max(lds_a, lds_b);
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  *out = c;
+  return IQLHIP_OK;
+}
+
+static void drop_graph(iqlhip_ctx* c) {
+  if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+  if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+  c->gkey = GraphKey();
+}
+
+extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
+  if (!c) return IQLHIP_OK;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  drop_graph(c);
+  for (hipEvent_t e : c->ev) hipEventDestroy(e);
+  if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+  hipFree(c->sc.h0); hipFree(c->sc.h1); hipFree(c->sc.heads); hipFree(c->sc.slab_a); hipFree(c->sc.slab_b);
+  hipFree(c->sc.loss_parts); hipFree(c->sc.losses); hipFree(c->flat_tmp); hipFree(c->loss_ring);
+  hipFree(c->idx_chunk); hipFree(c->sched); hipFree(c->hdr);
+  delete c;
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_set_hyper(iqlhip_ctx* c, const iqlhip_hyper* h) {
+  if (!c || !h) return fail(IQLHIP_EINVAL, "NULL argument");
+  c->hyper = *h;
+  drop_graph(c);
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_bind(iqlhip_ctx* c, float* params, float* target, float* m, float* v) {
+  if (!c || !params || !target || !m || !v) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (((uintptr_t)params | (uintptr_t)target | (uintptr_t)m | (uintptr_t)v) & 15)
+    return fail(IQLHIP_EINVAL, "arenas must be 16-byte aligned");
+  c->params = params; c->target = target; c->m = m; c->v = v;
+  drop_graph(c);
+  return IQLHIP_OK;
+}
+
+extern "C" int64_t iqlhip_grad_words(const iqlhip_ctx* c) { return c ? c->L.n_params + 4 : 0; }
+
+// ---------------------------------------------------------------------------
+static int check_batch(const iqlhip_ctx* c, const iqlhip_batch* b) {
+  if (!c->params) return fail(IQLHIP_ENOTBOUND, "iqlhip_bind has not been called");
+  if (!b) return fail(IQLHIP_EINVAL, "batch is NULL");
+  if (b->rows < 1 || b->rows > c->dims.max_batch)
+    return fail(IQLHIP_EINVAL, "batch rows %d outside [1, max_batch=%d]", b->rows, c->dims.max_batch);
+  if (!b->s_dev || !b->a_dev || !b->r_dev || !b->ns_dev || !b->d_dev) return fail(IQLHIP_EINVAL, "NULL batch tensor");
+  if (b->ld_s < c->dims.state_dim || b->ld_ns < c->dims.state_dim || b->ld_a < c->dims.action_dim || b->ld_r < 1 ||
+      b->ld_d < 1)
+    return fail(IQLHIP_EINVAL, "batch row strides smaller than the row widths");
+  return IQLHIP_OK;
+}
+
+static StepParams make_step(const iqlhip_ctx* c, const iqlhip_batch* b, float inv_batch) {
+  StepParams p;
+  p.L = c->L;
+  p.hy = c->hyper;
+  p.params = c->params;
+  p.target = c->target;
+  p.sc = c->sc;
+  p.b.s = b->s_dev; p.b.a = b->a_dev; p.b.r = b->r_dev; p.b.ns = b->ns_dev; p.b.d = b->d_dev;
+  p.b.ld_s = b->ld_s; p.b.ld_a = b->ld_a; p.b.ld_r = b->ld_r; p.b.ld_ns = b->ld_ns; p.b.ld_d = b->ld_d;
+  p.b.idx = (const long long*)b->idx_dev;
+  p.b.rows = b->rows;
+  p.S = c->dims.state_dim;
+  p.A = c->dims.action_dim;
+  p.policy = c->dims.policy;
+  p.inv_batch = inv_batch;
+  return p;
+}
+
+static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, int rows, const float* flat) {
+  UpdParams u;
+  u.L = c->L;
+  u.sc = *sc;
+  u.tau = c->hyper.tau;
+  u.one_minus_tau = c->hyper.one_minus_tau;
+  u.params = c->params; u.target = c->target; u.m = c->m; u.v = c->v;
+  u.slab_a = c->sc.slab_a; u.slab_b = c->sc.slab_b;
+  for (int n = 0; n < 4; ++n) u.slab_b_off[n] = c->sc.slab_b_off[n];
+  u.flat_grads = flat;
+  u.loss_parts = c->sc.loss_parts;
+  u.losses = c->sc.losses;
+  u.loss_ring = nullptr;
+  u.ring_slot = 0;
+  u.n_chunk = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  u.n_rt = (rows + RT_ROWS - 1) / RT_ROWS;
+  u.batch_rows = rows;
+  u.sched = nullptr;
+  u.sched_idx = 0;
+  return u;
+}
+
+static void launch_fwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
+  const int n_rt = (p.b.rows + RT_ROWS - 1) / RT_ROWS;
+  hipLaunchKernelGGL(iql_fwd_kernel, dim3(8 * n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
+}
+static void launch_bwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
+  const int n_rt = (p.b.rows + RT_ROWS - 1) / RT_ROWS;
+  const int n_chunk = (p.b.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  const int per_net = 32 * n_chunk + 4 * n_rt;
+  hipLaunchKernelGGL(iql_bwd_kernel, dim3(8 * ((per_net + 1) / 2)), dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+}
+static void launch_upd(const iqlhip_ctx* c, const UpdParams& u, hipStream_t st) {
+  const int nb = (int)((c->L.n_params / 4 + 255) / 256);
+  hipLaunchKernelGGL(iql_update_kernel, dim3(nb), dim3(256), 0, st, u);
+}
+
+static int ensure_events(iqlhip_ctx* c, int n) {
+  while ((int)c->ev.size() < n) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    c->ev.push_back(e);
+  }
+  return IQLHIP_OK;
+}
+
+static int harvest_timing(iqlhip_ctx* c) {
+  for (int i = 0; i + 3 < c->ev_used; i += 4) {
+    HIPCHK(hipEventSynchronize(c->ev[i + 3]));
+    float a = 0, b = 0, d = 0;
+    HIPCHK(hipEventElapsedTime(&a, c->ev[i], c->ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&b, c->ev[i + 1], c->ev[i + 2]));
+    HIPCHK(hipEventElapsedTime(&d, c->ev[i + 2], c->ev[i + 3]));
+    c->t_acc[0] += a * 1e3f; c->t_acc[1] += b * 1e3f; c->t_acc[2] += d * 1e3f; c->t_acc[3] += (a + b + d) * 1e3f;
+    c->t_n += 1;
+  }
+  c->ev_used = 0;
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_set_timing(iqlhip_ctx* c, int enabled) {
+  if (!c) return fail(IQLHIP_EINVAL, "NULL ctx");
+  c->timing = enabled != 0;
+  c->ev_used = 0;
+  c->t_n = 0;
+  for (float& t : c->t_acc) t = 0.f;
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_get_timing(iqlhip_ctx* c, float out_us[4]) {
+  if (!c || !out_us) return fail(IQLHIP_EINVAL, "NULL argument");
+  int rc = harvest_timing(c);
+  if (rc) return rc;
+  for (int k = 0; k < 4; ++k) out_us[k] = c->t_n ? c->t_acc[k] / c->t_n : 0.f;
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_scalars* sc, void* stream) {
+  if (!c || !sc) return fail(IQLHIP_EINVAL, "NULL argument");
+  int rc = check_batch(c, b);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  StepParams p = make_step(c, b, sc->inv_batch);
+  UpdParams u = make_upd(c, sc, b->rows, nullptr);
+  hipEvent_t* ev = nullptr;
+  if (c->timing) {
+    if (c->ev_used + 4 > 4096) { rc = harvest_timing(c); if (rc) return rc; }
+    rc = ensure_events(c, c->ev_used + 4);
+    if (rc) return rc;
+    ev = &c->ev[c->ev_used];
+    c->ev_used += 4;
+    HIPCHK(hipEventRecord(ev[0], st));
+  }
+  launch_fwd(c, p, st);
+  if (ev) HIPCHK(hipEventRecord(ev[1], st));
+  launch_bwd(c, p, st);
+  if (ev) HIPCHK(hipEventRecord(ev[2], st));
+  launch_upd(c, u, st);
+  if (ev) HIPCHK(hipEventRecord(ev[3], st));
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_scalars* sc,
+                                       float* grads_dev, void* stream) {
+  if (!c || !sc || !grads_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  int rc = check_batch(c, b);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  StepParams p = make_step(c, b, sc->inv_batch);
+  UpdParams u = make_upd(c, sc, b->rows, nullptr);
+  launch_fwd(c, p, st);
+  launch_bwd(c, p, st);
+  const int nb = (int)((c->L.n_params / 4 + 255) / 256);
+  hipLaunchKernelGGL(iql_grad_flatten_kernel, dim3(nb), dim3(256), 0, st, u, grads_dev);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_apply_update(iqlhip_ctx* c, const float* grads_dev, const iqlhip_step_scalars* sc, void* stream) {
+  if (!c || !sc || !grads_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (!c->params) return fail(IQLHIP_ENOTBOUND, "iqlhip_bind has not been called");
+  UpdParams u = make_upd(c, sc, 1, grads_dev);
+  launch_upd(c, u, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_read_losses(iqlhip_ctx* c, float out[3], void* stream) {
+  if (!c || !out) return fail(IQLHIP_EINVAL, "NULL argument");
+  float h[4];
+  HIPCHK(hipMemcpyAsync(h, c->sc.losses, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_read_loss_ring(iqlhip_ctx* c, float* out, int32_t n_steps, void* stream) {
+  if (!c || !out) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (n_steps < 1 || n_steps > c->ring_cap) return fail(IQLHIP_EINVAL, "n_steps outside [1,%d]", c->ring_cap);
+  std::vector<float> h((size_t)n_steps * 4);
+  HIPCHK(hipMemcpyAsync(h.data(), c->loss_ring, h.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  for (int k = 0; k < n_steps; ++k)
+    for (int j = 0; j < 3; ++j) out[3 * k + j] = h[4 * (size_t)k + j];
+  return IQLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed, uint64_t offset, void* stream) {
+  if (!idx_dev || n < 1 || size < 1) return fail(IQLHIP_EINVAL, "bad argument");
+  const int nb = (int)std::min<int64_t>((n / 2 + 255) / 256 + 1, 1024);
+  hipLaunchKernelGGL(iql_draw_indices_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (long long*)idx_dev,
+                     (long long)n, (long long)size, (unsigned long long)seed, (unsigned long long)offset,
+                     (const unsigned long long*)nullptr);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t ld, int64_t size, int32_t B,
+                                  const iqlhip_step_scalars* sc, int32_t K, uint64_t seed, uint64_t stream_offset,
+                                  void* stream) {
+  if (!c || !rows_dev || !sc) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (!c->params) return fail(IQLHIP_ENOTBOUND, "iqlhip_bind has not been called");
+  if (K < 1 || K > c->k_max) return fail(IQLHIP_EINVAL, "n_steps outside [1,%d]", c->k_max);
+  if (B < 1 || B > c->dims.max_batch) return fail(IQLHIP_EINVAL, "batch_rows outside [1,max_batch]");
+  if (size < 1) return fail(IQLHIP_EINVAL, "empty buffer");
+  const int S = c->dims.state_dim, A = c->dims.action_dim;
+  if (ld < 2 * S + A + 2) return fail(IQLHIP_EINVAL, "row stride too small");
+  hipStream_t st = (hipStream_t)stream;
+  GraphKey key;
+  key.rows = rows_dev; key.ld = ld; key.B = B; key.K = K; key.params = c->params;
+  if (!(c->gexec && c->gkey == key)) {
+    drop_graph(c);
+    hipStream_t cs = c->cap_stream;
+    HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    {
+      const long long n = (long long)K * B;
+      const int nb = (int)std::min<long long>((n / 2 + 255) / 256 + 1, 1024);
+      hipLaunchKernelGGL(iql_draw_indices_kernel, dim3(nb), dim3(256), 0, cs, c->idx_chunk, n, (long long)size,
+                         0ull, 0ull, (const unsigned long long*)c->hdr);
+    }
+    for (int k = 0; k < K; ++k) {
+      iqlhip_batch b;
+      b.s_dev = rows_dev; b.a_dev = rows_dev + S; b.ns_dev = rows_dev + S + A;
+      b.r_dev = rows_dev + 2 * S + A; b.d_dev = rows_dev + 2 * S + A + 1;
+      b.ld_s = b.ld_a = b.ld_r = b.ld_ns = b.ld_d = ld;
+      b.idx_dev = (const int64_t*)(c->idx_chunk + (long long)k * B);
+      b.rows = B;
+      StepParams p = make_step(c, &b, sc[0].inv_batch);
+      UpdParams u = make_upd(c, &sc[0], B, nullptr);
+      u.sched = c->sched;
+      u.sched_idx = k;
+      u.loss_ring = c->loss_ring;
+      u.ring_slot = k;
+      launch_fwd(c, p, cs);
+      launch_bwd(c, p, cs);
+      launch_upd(c, u, cs);
+    }
+    hipError_t e = hipStreamEndCapture(cs, &c->graph);
+    if (e != hipSuccess) return fail(IQLHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    HIPCHK(hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
+    c->gkey = key;
+  }
+  unsigned long long hdr[4] = {(unsigned long long)size, (unsigned long long)seed, (unsigned long long)stream_offset, 0};
+  HIPCHK(hipMemcpyAsync(c->hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->sched, sc, (size_t)K * sizeof(iqlhip_step_scalars), hipMemcpyHostToDevice, st));
+  hipEvent_t* ev = nullptr;
+  if (c->timing) {
+    int rc = ensure_events(c, c->ev_used + 2);
+    if (rc) return rc;
+    ev = &c->ev[c->ev_used];
+    HIPCHK(hipEventRecord(ev[0], st));
+  }
+  HIPCHK(hipGraphLaunch(c->gexec, st));
+  if (ev) {
+    HIPCHK(hipEventRecord(ev[1], st));
+    HIPCHK(hipEventSynchronize(ev[1]));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    c->t_acc[3] += ms * 1e3f;   // total per chunk; per-step = /K done by the caller
+    c->t_n += 1;
+  }
+  return IQLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int iqlhip_rows_write(float* rows_dev, int64_t ld, int32_t S, int32_t A, int64_t row0, int64_t n,
+                                 const float* s, const float* a, const float* r, const float* ns, const float* d,
+                                 void* stream) {
+  if (!rows_dev || !s || !a || !r || !ns || !d) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (n < 0 || row0 < 0 || ld < 2 * (int64_t)S + A + 2) return fail(IQLHIP_EINVAL, "bad rows_write geometry");
+  if (n == 0) return IQLHIP_OK;
+  const long long total = (long long)n * (2 * S + A + 2);
+  const int nb = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(iql_rows_write_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows_dev, (long long)ld, S, A,
+                     (long long)row0, (long long)n, s, a, r, ns, d);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t S, int32_t A, const int64_t* idx_dev,
+                                  int64_t n, float* s, float* a, float* r, float* ns, float* d, void* stream) {
+  if (!rows_dev || !idx_dev || !s || !a || !r || !ns || !d) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (n < 0 || ld < 2 * (int64_t)S + A + 2) return fail(IQLHIP_EINVAL, "bad rows_gather geometry");
+  if (n == 0) return IQLHIP_OK;
+  const long long total = (long long)n * (2 * S + A + 2);
+  const int nb = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(iql_rows_gather_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows_dev, (long long)ld, S, A,
+                     (const long long*)idx_dev, (long long)n, s, a, r, ns, d);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int iqlhip_debug_read(iqlhip_ctx* c, const char* name, float* host_out, int64_t max_floats, int64_t* n_out,
+                                 void* stream) {
+  if (!c || !name || !host_out) return fail(IQLHIP_EINVAL, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  const float* src = nullptr;
+  int64_t n = 0;
+  const int MB = c->dims.max_batch;
+  if (!strcmp(name, "h0")) { src = c->sc.h0; n = (int64_t)4 * MB * HID; }
+  else if (!strcmp(name, "h1")) { src = c->sc.h1; n = (int64_t)4 * MB * HID; }
+  else if (!strcmp(name, "heads")) { src = c->sc.heads; n = (int64_t)6 * NSPLIT * MB + (int64_t)NSPLIT * MB * c->dims.action_dim; }
+  else if (!strcmp(name, "loss_parts")) { src = c->sc.loss_parts; n = 4 * 64; }
+  else if (!strcmp(name, "grads")) {
+    // flatten the slabs of the LAST forward_backward/step with the batch size implied by max_batch slabs in use
+    return fail(IQLHIP_EINVAL, "use iqlhip_forward_backward to obtain the flat gradient");
+  } else return fail(IQLHIP_EINVAL, "unknown scratch array '%s'", name);
+  if (n > max_floats) n = max_floats;
+  HIPCHK(hipMemcpyAsync(host_out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (n_out) *n_out = n;
+  return IQLHIP_OK;
+}

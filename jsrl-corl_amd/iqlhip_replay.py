@@ -1,0 +1,165 @@
+"""ReplayBuffer with the reference's surface (algorithms/finetune/iql.py:122-197)
+on top of ONE packed row store  [s(S) | a(A) | s'(S) | r | d | pad]  (row stride
+a multiple of 16 B) instead of five separate tensors, so that a sampled
+transition is one contiguous 168..448-byte read instead of five 4..156-byte ones.
+
+On a GPU device the row writes and the five-way gather of `sample` run in
+libiqlhip.so (iqlhip_rows_write / iqlhip_rows_gather); the index draw stays
+`np.random.randint` on the host exactly like the reference (iql.py:172), so a
+seeded run draws the same index stream.  On a CPU device (no GPU in the
+process: host-logic tests, config-1 plumbing) the same storage is addressed
+with torch indexing; the training step itself has no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+import iqlhip_binding as hb
+
+TensorBatch = List[torch.Tensor]
+
+
+def _is_gpu(device) -> bool:
+    return torch.device(device).type == "cuda"
+
+
+class ReplayBuffer:
+    def __init__(self, state_dim: int, action_dim: int, buffer_size: int, device: str = "cpu"):
+        self._buffer_size = buffer_size
+        self._pointer = 0
+        self._size = 0
+        self._state_dim = state_dim
+        self._action_dim = action_dim
+        self._device = device
+        self._gpu = _is_gpu(device)
+        w = 2 * state_dim + action_dim + 2
+        self._ld = hb.row_stride(state_dim, action_dim) if self._gpu else (w + 3) // 4 * 4
+        self._rows = torch.zeros((buffer_size, self._ld), dtype=torch.float32, device=device)
+
+    # ---- views with the reference's attribute names (iql.py:134-146) ------
+    @property
+    def _states(self) -> torch.Tensor:
+        return self._rows[:, : self._state_dim]
+
+    @property
+    def _actions(self) -> torch.Tensor:
+        return self._rows[:, self._state_dim: self._state_dim + self._action_dim]
+
+    @property
+    def _next_states(self) -> torch.Tensor:
+        o = self._state_dim + self._action_dim
+        return self._rows[:, o: o + self._state_dim]
+
+    @property
+    def _rewards(self) -> torch.Tensor:
+        o = 2 * self._state_dim + self._action_dim
+        return self._rows[:, o: o + 1]
+
+    @property
+    def _dones(self) -> torch.Tensor:
+        o = 2 * self._state_dim + self._action_dim + 1
+        return self._rows[:, o: o + 1]
+
+    def _to_tensor(self, data: np.ndarray) -> torch.Tensor:
+        return torch.tensor(data, dtype=torch.float32, device=self._device)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self._rows.device).cuda_stream
+
+    def _write_rows(self, row0: int, s, a, r, ns, d) -> None:
+        n = s.shape[0]
+        if self._gpu:
+            s, a, r, ns, d = (t.contiguous() for t in (s, a, r, ns, d))
+            hb.check(hb.lib().iqlhip_rows_write(
+                self._rows.data_ptr(), self._ld, self._state_dim, self._action_dim, row0, n,
+                s.data_ptr(), a.data_ptr(), r.data_ptr(), ns.data_ptr(), d.data_ptr(), self._stream()))
+        else:
+            S, A = self._state_dim, self._action_dim
+            blk = self._rows[row0: row0 + n]
+            blk[:, :S] = s
+            blk[:, S: S + A] = a
+            blk[:, S + A: 2 * S + A] = ns
+            blk[:, 2 * S + A] = r.reshape(-1)
+            blk[:, 2 * S + A + 1] = d.reshape(-1)
+
+    # Loads data in d4rl format, i.e. from Dict[str, np.array] (iql.py:153-169).
+    def load_d4rl_dataset(self, data: Dict[str, np.ndarray]):
+        if self._size != 0:
+            raise ValueError("Trying to load data into non-empty replay buffer")
+        n_transitions = data["observations"].shape[0]
+        if n_transitions > self._buffer_size:
+            raise ValueError("Replay buffer is smaller than the dataset you are trying to load!")
+        chunk = 1 << 20  # bound the staging copies for 10M-row datasets
+        for lo in range(0, n_transitions, chunk):
+            hi = min(lo + chunk, n_transitions)
+            self._write_rows(
+                lo,
+                self._to_tensor(data["observations"][lo:hi]),
+                self._to_tensor(data["actions"][lo:hi]),
+                self._to_tensor(data["rewards"][lo:hi]),
+                self._to_tensor(data["next_observations"][lo:hi]),
+                self._to_tensor(data["terminals"][lo:hi]),
+            )
+        self._size += n_transitions
+        self._pointer = min(self._size, n_transitions)
+        print(f"Dataset size: {n_transitions}")
+
+    def _index_bound(self) -> int:
+        return self._size
+
+    def sample_indices(self, batch_size: int) -> torch.Tensor:
+        """The reference's host index draw (global numpy RNG), as a device int64 tensor."""
+        indices = np.random.randint(0, self._index_bound(), size=batch_size)
+        return torch.from_numpy(indices).to(self._rows.device, non_blocking=False)
+
+    def gather(self, idx: torch.Tensor) -> TensorBatch:
+        n = idx.shape[0]
+        S, A = self._state_dim, self._action_dim
+        if not self._gpu:
+            rows = self._rows[idx]
+            return [rows[:, :S].contiguous(), rows[:, S: S + A].contiguous(),
+                    rows[:, 2 * S + A: 2 * S + A + 1].contiguous(), rows[:, S + A: 2 * S + A].contiguous(),
+                    rows[:, 2 * S + A + 1: 2 * S + A + 2].contiguous()]
+        dev = self._rows.device
+        out = [torch.empty((n, S), dtype=torch.float32, device=dev),
+               torch.empty((n, A), dtype=torch.float32, device=dev),
+               torch.empty((n, 1), dtype=torch.float32, device=dev),
+               torch.empty((n, S), dtype=torch.float32, device=dev),
+               torch.empty((n, 1), dtype=torch.float32, device=dev)]
+        hb.check(hb.lib().iqlhip_rows_gather(
+            self._rows.data_ptr(), self._ld, S, A, idx.data_ptr(), n,
+            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(),
+            self._stream()))
+        return out
+
+    def sample(self, batch_size: int) -> TensorBatch:
+        # order: states, actions, rewards(B,1), next_states, dones(B,1)  (iql.py:171-178)
+        return self.gather(self.sample_indices(batch_size))
+
+    def add_transition(self, state: np.ndarray, action: np.ndarray, reward: float, next_state: np.ndarray,
+                       done: bool):
+        # one packed host row, one H2D copy (the reference issues five, iql.py:189-193)
+        S, A = self._state_dim, self._action_dim
+        row = np.zeros((self._ld,), dtype=np.float32)
+        row[:S] = np.asarray(state, dtype=np.float32).reshape(-1)
+        row[S: S + A] = np.asarray(action, dtype=np.float32).reshape(-1)
+        row[S + A: 2 * S + A] = np.asarray(next_state, dtype=np.float32).reshape(-1)
+        row[2 * S + A] = np.float32(reward)
+        row[2 * S + A + 1] = np.float32(done)
+        self._rows[self._pointer].copy_(torch.from_numpy(row))
+        self._pointer = (self._pointer + 1) % self._buffer_size
+        self._size = min(self._size + 1, self._buffer_size)
+
+
+class OfflineReplayBuffer(ReplayBuffer):
+    """algorithms/offline/iql.py:125-184 flavour: sample bounded by min(size, pointer),
+    add_transition unimplemented."""
+
+    def _index_bound(self) -> int:
+        return min(self._size, self._pointer)
+
+    def add_transition(self, *args, **kwargs):
+        raise NotImplementedError

@@ -1,0 +1,489 @@
+"""ImplicitQLearning with the reference's constructor, attributes and checkpoint
+format (algorithms/finetune/iql.py:445-606) whose train() runs the whole step
+— 7 MLP forwards, 3 losses, backward, 3 Adam updates, Polyak — in libiqlhip.so
+(hand-written HIP for gfx950) instead of ~700 aten calls.
+
+Ownership model: the caller constructs the nn.Modules and the
+torch.optim.Adam objects and passes them in.  On a GPU device this class
+re-homes every nn.Parameter's storage into ONE flat fp32 arena (layout:
+iqlhip_arena_layout) and the Adam moments into two more, so the C ABI sees
+three pointers; the Parameter / optimizer objects the caller holds stay the
+same Python objects and stay usable (actor.act(), state_dict(), isinstance).
+
+There is no CPU implementation of the step: with a CPU device the object can
+be constructed, checkpointed and inspected (host logic), but train() raises.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import warnings
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.optim.lr_scheduler import CosineAnnealingLR
+
+import iqlhip_binding as hb
+from iqlhip_networks import (DeterministicPolicy, GaussianPolicy, LOG_STD_MAX, LOG_STD_MIN, dropout_p,
+                             linear_layers)
+
+TensorBatch = List[torch.Tensor]
+EXP_ADV_MAX = 100.0
+K_MAX = 1024  # steps per captured hipGraph chunk (library limit)
+
+
+def _is_gpu(device) -> bool:
+    return torch.device(device).type == "cuda"
+
+
+def _mlp_tensors(module: nn.Module) -> Dict[str, nn.Parameter]:
+    lin = linear_layers(module)
+    if len(lin) != 3:
+        raise NotImplementedError(
+            f"iqlhip kernels are built for 2 hidden layers (3 Linear layers); this network has {len(lin)}")
+    return {"w0": lin[0].weight, "b0": lin[0].bias, "w1": lin[1].weight, "b1": lin[1].bias,
+            "w2": lin[2].weight, "b2": lin[2].bias}
+
+
+class ImplicitQLearning:
+    def __init__(self, max_action: float, actor: nn.Module, actor_optimizer: torch.optim.Optimizer,
+                 q_network: nn.Module, q_optimizer: torch.optim.Optimizer, v_network: nn.Module,
+                 v_optimizer: torch.optim.Optimizer, iql_tau: float = 0.7, beta: float = 3.0,
+                 max_steps: int = 1000000, discount: float = 0.99, tau: float = 0.005, device: str = "cpu"):
+        self.max_action = max_action
+        self.qf = q_network
+        self.q_target = copy.deepcopy(self.qf).requires_grad_(False).to(device)
+        self.vf = v_network
+        self.actor = actor
+        self.v_optimizer = v_optimizer
+        self.q_optimizer = q_optimizer
+        self.actor_optimizer = actor_optimizer
+        if max_steps is not None:
+            self.actor_lr_schedule = CosineAnnealingLR(self.actor_optimizer, max_steps)
+        else:
+            self.actor_lr_schedule = None
+        self.iql_tau = iql_tau
+        self.beta = beta
+        self.discount = discount
+        self.tau = tau
+
+        self.total_it = 0
+        self.device = device
+
+        # data-parallel state (set by enable_data_parallel)
+        self._dp_group = None
+        self._dp_world = 1
+
+        self._ctx = None
+        self._max_batch = 0
+        self._adam_t = {"v": 0, "q": 0, "pi": 0}
+        self._hyper_sent = None
+        if _is_gpu(device):
+            self._attach(max_batch=256)
+
+    # ------------------------------------------------------------------ arenas
+    def _net_tensors(self) -> Dict[str, Dict[str, nn.Parameter]]:
+        nets = {"vf": _mlp_tensors(self.vf), "q1": _mlp_tensors(self.qf.q1), "q2": _mlp_tensors(self.qf.q2),
+                "pi": _mlp_tensors(self.actor.net)}
+        if hasattr(self.actor, "log_std"):
+            nets["pi"]["log_std"] = self.actor.log_std
+        return nets
+
+    def _target_tensors(self) -> Dict[str, Dict[str, nn.Parameter]]:
+        return {"q1": _mlp_tensors(self.q_target.q1), "q2": _mlp_tensors(self.q_target.q2)}
+
+    def _probe_dims(self) -> Tuple[int, int, bool]:
+        nets = self._net_tensors()
+        S = nets["vf"]["w0"].shape[1]
+        A = nets["pi"]["w2"].shape[0]
+        hid = nets["vf"]["w0"].shape[0]
+        ok = (nets["q1"]["w0"].shape[1] == S + A and nets["q2"]["w0"].shape[1] == S + A
+              and nets["pi"]["w0"].shape[1] == S and nets["vf"]["w2"].shape[0] == 1)
+        for t in nets.values():
+            ok = ok and t["w0"].shape[0] == hid and tuple(t["w1"].shape) == (hid, hid) and t["w2"].shape[1] == hid
+        if not ok:
+            raise NotImplementedError("network shapes are not the IQL TwinQ / ValueFunction / policy MLP family")
+        if hid != hb.IQLHIP_HIDDEN:
+            raise NotImplementedError(f"iqlhip kernels are tiled for hidden_dim={hb.IQLHIP_HIDDEN}, got {hid}")
+        if dropout_p(self.actor) > 0.0:
+            raise NotImplementedError("actor dropout > 0 is not implemented in the HIP step yet")
+        gaussian = "log_std" in nets["pi"]
+        if not gaussian and not isinstance(self.actor, DeterministicPolicy) and not hasattr(self.actor, "net"):
+            raise NotImplementedError("unknown policy class")
+        return S, A, gaussian
+
+    def _segments(self, L, nets, which: str):
+        """yield (parameter, offset_in_arena) for every tensor of `nets`."""
+        order = {"vf": hb.NET_V, "q1": hb.NET_Q1, "q2": hb.NET_Q2, "pi": hb.NET_PI}
+        for name, tensors in nets.items():
+            nl = L.net[order[name]]
+            shift = L.target_src if which == "target" else 0
+            for key, p in tensors.items():
+                yield p, int(getattr(nl, key)) - shift
+
+    def _attach(self, max_batch: int) -> None:
+        """(Re)build the flat arenas + the library context for `max_batch` rows."""
+        S, A, gaussian = self._probe_dims()
+        dev = torch.device(self.device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        L = hb.arena_layout(S, A, gaussian, max_batch)
+        old = None
+        if self._ctx is not None:
+            old = (self._params_arena, self._target_arena, self._m_arena, self._v_arena)
+            self._release()
+        self._S, self._A, self._gaussian, self._layout = S, A, gaussian, L
+        if old is None:
+            self._params_arena = torch.zeros(L.n_params, dtype=torch.float32, device=dev)
+            self._target_arena = torch.zeros(L.n_target, dtype=torch.float32, device=dev)
+            self._m_arena = torch.zeros(L.n_params, dtype=torch.float32, device=dev)
+            self._v_arena = torch.zeros(L.n_params, dtype=torch.float32, device=dev)
+            self._rehome(self._net_tensors(), self._params_arena, "params")
+            self._rehome(self._target_tensors(), self._target_arena, "target")
+            self._absorb_opt_state()
+        else:
+            self._params_arena, self._target_arena, self._m_arena, self._v_arena = old
+        self._dev = dev
+        d = hb.Dims(S, A, hb.IQLHIP_HIDDEN, 2, hb.POLICY_GAUSSIAN if gaussian else hb.POLICY_DETERMINISTIC, max_batch)
+        h = self._hyper_struct()
+        ctx = C.c_void_p()
+        hb.check(hb.lib().iqlhip_create(C.byref(d), C.byref(h), dev.index, C.byref(ctx)))
+        self._ctx = ctx
+        self._hyper_sent = self._hyper_tuple()
+        self._max_batch = max_batch
+        hb.check(hb.lib().iqlhip_bind(self._ctx, self._params_arena.data_ptr(), self._target_arena.data_ptr(),
+                                      self._m_arena.data_ptr(), self._v_arena.data_ptr()))
+
+    def _rehome(self, nets, arena: torch.Tensor, which: str) -> None:
+        with torch.no_grad():
+            for p, off in self._segments(self._layout, nets, which):
+                view = arena[off: off + p.numel()].view(p.shape)
+                view.copy_(p.data.to(arena.device, torch.float32))
+                p.data = view
+
+    def _param_offsets(self):
+        return list(self._segments(self._layout, self._net_tensors(), "params"))
+
+    def _optimizer_of(self, p) -> torch.optim.Optimizer:
+        for opt in (self.v_optimizer, self.q_optimizer, self.actor_optimizer):
+            for grp in opt.param_groups:
+                if any(p is q for q in grp["params"]):
+                    return opt
+        raise ValueError("parameter is not owned by any of the three optimizers")
+
+    def _absorb_opt_state(self) -> None:
+        """Copy existing Adam moments (e.g. after optimizer.load_state_dict) into the flat
+        arenas and re-point the optimizer's state tensors at the arena views."""
+        with torch.no_grad():
+            for grp_name, opt in (("v", self.v_optimizer), ("q", self.q_optimizer), ("pi", self.actor_optimizer)):
+                t = 0
+                for st in opt.state.values():
+                    if "step" in st:
+                        t = max(t, int(float(st["step"])))
+                self._adam_t[grp_name] = t
+            for p, off in self._param_offsets():
+                opt = self._optimizer_of(p)
+                st = opt.state.get(p, None)
+                mv = self._m_arena[off: off + p.numel()].view(p.shape)
+                vv = self._v_arena[off: off + p.numel()].view(p.shape)
+                if st and "exp_avg" in st:
+                    mv.copy_(st["exp_avg"].to(mv.device, torch.float32))
+                    vv.copy_(st["exp_avg_sq"].to(vv.device, torch.float32))
+                    st["exp_avg"], st["exp_avg_sq"] = mv, vv
+                else:
+                    mv.zero_()
+                    vv.zero_()
+
+    def _sync_opt_state(self) -> None:
+        """Make optimizer.state look like torch.optim.Adam's after `t` steps (for state_dict())."""
+        if self._ctx is None:
+            return
+        groups = {"v": self.v_optimizer, "q": self.q_optimizer, "pi": self.actor_optimizer}
+        for p, off in self._param_offsets():
+            opt = self._optimizer_of(p)
+            grp_name = next(k for k, o in groups.items() if o is opt)
+            t = self._adam_t[grp_name]
+            if t == 0 and p not in opt.state:
+                continue  # torch creates Adam state lazily at the first step
+            st = opt.state[p]
+            st["step"] = torch.tensor(float(t), dtype=torch.float32)
+            st["exp_avg"] = self._m_arena[off: off + p.numel()].view(p.shape)
+            st["exp_avg_sq"] = self._v_arena[off: off + p.numel()].view(p.shape)
+
+    def _release(self) -> None:
+        if self._ctx is not None:
+            hb.check(hb.lib().iqlhip_destroy(self._ctx))
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ scalars
+    def _hyper_tuple(self):
+        return (float(self.iql_tau), float(self.beta), float(self.discount), float(self.tau))
+
+    def _hyper_struct(self) -> hb.Hyper:
+        return hb.Hyper(self.iql_tau, self.beta, self.discount, self.tau, 1.0 - self.tau, EXP_ADV_MAX,
+                        LOG_STD_MIN, LOG_STD_MAX)
+
+    def _adam_hyper(self):
+        ref = None
+        for opt in (self.v_optimizer, self.q_optimizer, self.actor_optimizer):
+            if len(opt.param_groups) != 1:
+                raise NotImplementedError("one param group per optimizer expected (reference iql.py:673-675)")
+            g = opt.param_groups[0]
+            if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                raise NotImplementedError("iqlhip implements torch.optim.Adam defaults only (no weight decay/amsgrad)")
+            cur = (float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+            if ref is None:
+                ref = cur
+            elif cur != ref:
+                raise NotImplementedError("the three optimizers must share betas and eps")
+        return ref
+
+    def _fill_scalars(self, sc: hb.StepScalars, t: Dict[str, int], lrs: Dict[str, float], inv_batch: float) -> None:
+        b1, b2, eps = self._adam_hyper()
+        for i, g in enumerate(("v", "q", "pi")):
+            bc1 = 1.0 - b1 ** t[g]
+            bc2 = 1.0 - b2 ** t[g]
+            sc.step_size[i] = lrs[g] / bc1
+            sc.bc2_sqrt[i] = bc2 ** 0.5
+        sc.beta2 = b2
+        sc.one_minus_beta1 = 1.0 - b1
+        sc.one_minus_beta2 = 1.0 - b2
+        sc.eps = eps
+        sc.grad_scale = 1.0
+        sc.inv_batch = inv_batch
+
+    def _current_lrs(self) -> Dict[str, float]:
+        return {"v": float(self.v_optimizer.param_groups[0]["lr"]),
+                "q": float(self.q_optimizer.param_groups[0]["lr"]),
+                "pi": float(self.actor_optimizer.param_groups[0]["lr"])}
+
+    def _step_schedule(self) -> None:
+        if self.actor_lr_schedule is not None:
+            self.actor_optimizer._opt_called = True  # the Adam step ran inside libiqlhip
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self.actor_lr_schedule.step()
+
+    def _require_gpu(self) -> None:
+        if self._ctx is None:
+            raise RuntimeError(
+                "iqlhip: ImplicitQLearning.train needs a GPU device (device='cuda'); there is no CPU "
+                "implementation of the step in this package")
+
+    def _prepare(self, rows: int) -> None:
+        self._require_gpu()
+        if rows > self._max_batch:
+            self._attach(max_batch=(rows + 255) // 256 * 256)
+        if self._hyper_tuple() != self._hyper_sent:
+            h = self._hyper_struct()
+            hb.check(hb.lib().iqlhip_set_hyper(self._ctx, C.byref(h)))
+            self._hyper_sent = self._hyper_tuple()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self._dev).cuda_stream
+
+    def _as_dev(self, t: torch.Tensor) -> torch.Tensor:
+        if t.device != self._dev or t.dtype != torch.float32:
+            t = t.to(self._dev, torch.float32)
+        return t.contiguous()
+
+    def _batch_struct(self, batch: TensorBatch):
+        observations, actions, rewards, next_observations, dones = batch
+        if isinstance(self.actor, DeterministicPolicy) or not self._gaussian:
+            if actions.dim() != 2 or actions.shape[1] != self._A:
+                raise RuntimeError("Actions shape missmatch")
+        keep = [self._as_dev(x) for x in (observations, actions, rewards, next_observations, dones)]
+        o, a, r, no, d = keep
+        B = o.shape[0]
+        if o.dim() != 2 or o.shape[1] != self._S or tuple(no.shape) != (B, self._S) or tuple(a.shape) != (B, self._A):
+            raise ValueError(f"batch shapes do not match state_dim={self._S}, action_dim={self._A}")
+        if r.numel() != B or d.numel() != B:
+            raise ValueError("rewards / dones must have one element per row")
+        b = hb.Batch(o.data_ptr(), a.data_ptr(), r.data_ptr(), no.data_ptr(), d.data_ptr(),
+                     self._S, self._A, 1, self._S, 1, None, B)
+        return b, keep, B
+
+    # ------------------------------------------------------------------ the step
+    def train(self, batch: TensorBatch) -> Dict[str, float]:
+        """One IQL gradient step (iql.py:542-563).  Returns the three losses as floats
+        (one host sync instead of the reference's three .item() calls)."""
+        self._require_gpu()
+        b, keep, B = self._batch_struct(batch)
+        self._prepare(B)
+        self.total_it += 1
+        for g in self._adam_t:
+            self._adam_t[g] += 1
+        sc = hb.StepScalars()
+        lib = hb.lib()
+        out = (C.c_float * 3)()
+        if self._dp_world > 1:
+            self._fill_scalars(sc, self._adam_t, self._current_lrs(), 1.0 / (B * self._dp_world))
+            flat = self._dp_flat()
+            hb.check(lib.iqlhip_forward_backward(self._ctx, C.byref(b), C.byref(sc), flat.data_ptr(), self._stream()))
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self._dp_group)
+            hb.check(lib.iqlhip_apply_update(self._ctx, flat.data_ptr(), C.byref(sc), self._stream()))
+        else:
+            self._fill_scalars(sc, self._adam_t, self._current_lrs(), 1.0 / B)
+            hb.check(lib.iqlhip_step(self._ctx, C.byref(b), C.byref(sc), self._stream()))
+        self._step_schedule()
+        hb.check(lib.iqlhip_read_losses(self._ctx, out, self._stream()))
+        del keep
+        return {"value_loss": float(out[0]), "q_loss": float(out[1]), "actor_loss": float(out[2])}
+
+    def train_steps(self, replay_buffer, n_steps: int, batch_size: int, seed: int = 0,
+                    return_losses: bool = True) -> Optional[np.ndarray]:
+        """n_steps consecutive `sample -> train` iterations without host round trips
+        (the offline loop body, algorithms/offline/iql.py:631-635): indices are drawn on
+        the device (uniform with replacement, Philox keyed by (seed, total_it)), the
+        steps replay as one hipGraph per chunk of <= 1024, per-step Adam / cosine-LR
+        scalars are precomputed on the host.  Returns losses [n_steps,3] (value,q,actor)."""
+        self._prepare(batch_size)
+        if self._dp_world > 1:
+            raise NotImplementedError("train_steps is single-GPU; under data parallelism call train()")
+        if not getattr(replay_buffer, "_gpu", False):
+            raise ValueError("train_steps needs a ReplayBuffer that lives on the GPU")
+        size = replay_buffer._index_bound()
+        if size < 1:
+            raise ValueError("replay buffer is empty")
+        lib = hb.lib()
+        losses = np.empty((n_steps, 3), dtype=np.float32) if return_losses else None
+        done = 0
+        while done < n_steps:
+            k = min(K_MAX, n_steps - done)
+            arr = (hb.StepScalars * k)()
+            lrs = self._current_lrs()
+            for i in range(k):
+                for g in self._adam_t:
+                    self._adam_t[g] += 1
+                lrs["pi"] = float(self.actor_optimizer.param_groups[0]["lr"])
+                self._fill_scalars(arr[i], self._adam_t, lrs, 1.0 / batch_size)
+                self._step_schedule()
+            hb.check(lib.iqlhip_train_steps(
+                self._ctx, replay_buffer._rows.data_ptr(), replay_buffer._ld, size, batch_size, arr, k,
+                int(seed) & 0xFFFFFFFFFFFFFFFF, int(self.total_it) * ((batch_size + 1) // 2), self._stream()))
+            self.total_it += k
+            if return_losses:
+                buf = (C.c_float * (3 * k))()
+                hb.check(lib.iqlhip_read_loss_ring(self._ctx, buf, k, self._stream()))
+                losses[done: done + k] = np.frombuffer(buf, dtype=np.float32).reshape(k, 3)
+            done += k
+        return losses
+
+    # ------------------------------------------------------------------ data parallel
+    def enable_data_parallel(self, process_group=None) -> None:
+        """One process per GPU: parameters replicated, each rank trains on its
+        own rows, the flat gradient (+3 loss words) is all-reduced (RCCL, sum) between the
+        backward and the fused Adam/Polyak launch.  Call after torch.distributed is up."""
+        import torch.distributed as dist
+        self._require_gpu()
+        self._dp_group = process_group
+        self._dp_world = dist.get_world_size(process_group)
+        if self._dp_world > 1:
+            for arena in (self._params_arena, self._target_arena, self._m_arena, self._v_arena):
+                dist.broadcast(arena, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                               group=process_group)
+
+    def _dp_flat(self) -> torch.Tensor:
+        n = int(hb.lib().iqlhip_grad_words(self._ctx))
+        f = getattr(self, "_dp_flat_buf", None)
+        if f is None or f.numel() != n:
+            f = torch.zeros(n, dtype=torch.float32, device=self._dev)
+            self._dp_flat_buf = f
+        return f
+
+    # ------------------------------------------------------------------ checkpoints
+    def state_dict(self) -> Dict[str, Any]:
+        self._sync_opt_state()
+        if self.actor_lr_schedule is None:
+            lr_state_dict = {}
+        else:
+            lr_state_dict = self.actor_lr_schedule.state_dict()
+        return {
+            "qf": self.qf.state_dict(),
+            "q_optimizer": self.q_optimizer.state_dict(),
+            "vf": self.vf.state_dict(),
+            "v_optimizer": self.v_optimizer.state_dict(),
+            "actor": self.actor.state_dict(),
+            "actor_optimizer": self.actor_optimizer.state_dict(),
+            "actor_lr_schedule": lr_state_dict,
+            "total_it": self.total_it,
+        }
+
+    def _reset_target_from_qf(self) -> None:
+        # reference: q_target = copy.deepcopy(qf) WITHOUT requires_grad_(False) (iql.py:584, Appendix A quirk)
+        if self._ctx is None:
+            self.q_target = copy.deepcopy(self.qf)
+            return
+        L = self._layout
+        with torch.no_grad():
+            self._target_arena.copy_(self._params_arena[L.target_src: L.target_src + L.n_target])
+        new_t = copy.deepcopy(self.qf)   # fresh module object, like the reference
+        self.q_target = new_t
+        self._rehome(self._target_tensors(), self._target_arena, "target")
+
+    def load_state_dict(self, state_dict: Dict[str, Any]):
+        self.qf.load_state_dict(state_dict["qf"])
+        self.q_optimizer.load_state_dict(state_dict["q_optimizer"])
+        self._reset_target_from_qf()
+
+        self.vf.load_state_dict(state_dict["vf"])
+        self.v_optimizer.load_state_dict(state_dict["v_optimizer"])
+        self.actor.load_state_dict(state_dict["actor"])
+        self.actor_optimizer.load_state_dict(state_dict["actor_optimizer"])
+        if self.actor_lr_schedule is not None:
+            self.actor_lr_schedule.load_state_dict(state_dict["actor_lr_schedule"])
+
+        self.total_it = state_dict["total_it"]
+        if self._ctx is not None:
+            self._absorb_opt_state()
+
+    def partial_load_state_dict(self, state_dict: Dict[str, Any]):
+        """Load state dict, but don't load optimisers (iql.py:595-606)."""
+        self.qf.load_state_dict(state_dict["qf"])
+        self._reset_target_from_qf()
+
+        self.vf.load_state_dict(state_dict["vf"])
+
+        self.actor.load_state_dict(state_dict["actor"])
+        if self.actor_lr_schedule is not None:
+            self.actor_lr_schedule.load_state_dict(state_dict["actor_lr_schedule"])
+
+        self.total_it = state_dict["total_it"]
+
+    # ------------------------------------------------------------------ introspection for tests / bench
+    def set_timing(self, enabled: bool) -> None:
+        self._require_gpu()
+        hb.check(hb.lib().iqlhip_set_timing(self._ctx, 1 if enabled else 0))
+
+    def get_timing_us(self):
+        out = (C.c_float * 4)()
+        hb.check(hb.lib().iqlhip_get_timing(self._ctx, out))
+        return [float(x) for x in out]
+
+    def debug_read(self, name: str) -> np.ndarray:
+        self._require_gpu()
+        cap = 4 * self._max_batch * 256 + 64
+        buf = (C.c_float * cap)()
+        n = C.c_int64(0)
+        hb.check(hb.lib().iqlhip_debug_read(self._ctx, name.encode(), buf, cap, C.byref(n), self._stream()))
+        return np.frombuffer(buf, dtype=np.float32)[: n.value].copy()
+
+    def flat_gradient(self, batch: TensorBatch) -> np.ndarray:
+        """Forward+backward only; returns the flat gradient (+4 tail words) as numpy (tests)."""
+        b, keep, B = self._batch_struct(batch)
+        self._prepare(B)
+        sc = hb.StepScalars()
+        t1 = {g: max(1, v) for g, v in self._adam_t.items()}
+        self._fill_scalars(sc, t1, self._current_lrs(), 1.0 / (B * self._dp_world))
+        flat = self._dp_flat()
+        hb.check(hb.lib().iqlhip_forward_backward(self._ctx, C.byref(b), C.byref(sc), flat.data_ptr(), self._stream()))
+        torch.cuda.synchronize(self._dev)
+        return flat.cpu().numpy()

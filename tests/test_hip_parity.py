@@ -1,0 +1,158 @@
+"""GPU parity tests: the HIP step (through the C ABI, via the drop-in Python surface)
+against (i) the committed reference-generated goldens and (ii) the oracle on the
+same seeded inputs.  Tolerances are SURVEY.md §8(d)'s teacher-forced single-step
+protocol: losses rel <= 1e-5, gradients rel-to-max <= 3e-5 (fp32 summation-order
+noise on cancelling sums; the oracle itself sits at 1.1e-5 from the reference on one
+tensor), post-step parameters abs <= 2e-6, Adam moments rel-to-max <= 5e-5, target
+abs <= 1e-7*scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import (FREERUN_CASES, SINGLE_STEP_CASES, assert_losses, batch_from, check_step_against_golden,
+                     load_golden, single_step_inputs, sub)
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from hip_helpers import (build_hip_trainer, head_values, read_moments, read_params, to_torch_batch,
+                             unflatten_grads)
+    return build_hip_trainer, head_values, read_moments, read_params, to_torch_batch, unflatten_grads
+
+
+@pytest.mark.parametrize("name", SINGLE_STEP_CASES)
+def test_single_step_matches_reference_golden(name):
+    build, head_values, read_moments, read_params, to_tb, unflat = _hip()
+    z, meta = load_golden(name)
+    params, batch, hyper = single_step_inputs(meta)
+    tr = build(params, meta["S"], meta["A"], meta["gaussian"], hyper, meta["lrs"], meta["max_steps"])
+    tb = to_tb(batch)
+    flat = tr.flat_gradient(tb)
+    grads, lw = unflat(tr, flat)
+    hv = head_values(tr, params, meta["B"])
+    tq = np.minimum(hv["qt1"], hv["qt2"])
+    info = {"value_loss": lw[0], "q_loss": lw[1], "actor_loss": lw[2], "next_v": hv["next_v"],
+            "target_q": tq, "adv": tq - hv["v"], "grads": grads}
+    check_step_against_golden(z, meta, info, None, None, grad_rtol=3e-5, loss_rtol=1e-5)
+    log = tr.train(tb)
+    assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"], 1e-5)
+    assert tr.total_it == 1
+    check_step_against_golden(z, meta, None, read_params(tr), read_moments(tr), param_atol=2e-6,
+                              target_atol=1e-6)
+    # the cosine schedule advanced exactly like the reference's
+    assert abs(tr.actor_optimizer.param_groups[0]["lr"] - float(z["lr_after"][0])) < 1e-18
+
+
+@pytest.mark.parametrize("name", FREERUN_CASES)
+def test_free_run_10_steps_matches_reference(name):
+    build, _, _, read_params, to_tb, _ = _hip()
+    z, meta = load_golden(name)
+    S, A = meta["S"], meta["A"]
+    params = synth.synth_params(S, A, seed=meta["seed"], gaussian=meta["gaussian"])
+    data = synth.synth_transitions(meta["N"], S, A, seed=2000 + meta["seed"])
+    hyper = dict(meta["hyper"])
+    tr = build(params, S, A, meta["gaussian"], hyper, meta["lrs"], meta["max_steps"])
+    for k in range(meta["n_steps"]):
+        assert abs(tr.actor_optimizer.param_groups[0]["lr"] - z["actor_lr_used"][k]) < 1e-18
+        log = tr.train(to_tb(batch_from(data, z["indices"][k])))
+        assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"][k], 1e-5, what=f"step {k}")
+    got = read_params(tr)
+    for net, tensors in got.items():
+        for t, p in tensors.items():
+            want = z[f"param.{net}.{t}"]
+            assert np.max(np.abs(sub(p, meta["stride"]).reshape(want.shape) - want)) <= 2e-5, (net, t)
+
+
+def test_free_run_through_replay_buffer_and_numpy_rng():
+    """The loop call site H1: np.random.seed -> buffer.sample -> train reproduces
+    the reference's index stream and losses."""
+    import iql
+    build, _, _, _, _, _ = _hip()
+    z, meta = load_golden("g2_freerun_S17A6")
+    S, A, N = meta["S"], meta["A"], meta["N"]
+    params = synth.synth_params(S, A, seed=meta["seed"], gaussian=True)
+    data = synth.synth_transitions(N, S, A, seed=2000 + meta["seed"])
+    tr = build(params, S, A, True, dict(meta["hyper"]), meta["lrs"], meta["max_steps"])
+    buf = iql.ReplayBuffer(S, A, N, "cuda")
+    buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    np.random.seed(meta["seed"])
+    for k in range(meta["n_steps"]):
+        batch = buf.sample(meta["B"])
+        assert batch[2].shape == (meta["B"], 1) and batch[4].shape == (meta["B"], 1)
+        log = tr.train(batch)
+        assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"][k], 1e-5, what=f"step {k}")
+
+
+def test_step_matches_oracle_on_fresh_seeds():
+    """Oracle comparison on inputs no fixture covers (B=64 and B=512, S=11, A=3)."""
+    from oracle import iql_oracle as O
+    build, _, read_moments, read_params, to_tb, unflat = _hip()
+    for B, gaussian, seed in ((64, True, 301), (512, False, 302), (33, True, 303)):
+        S, A = 11, 3
+        params = synth.synth_params(S, A, seed=seed, gaussian=gaussian)
+        d = synth.synth_transitions(B, S, A, seed=seed + 1)
+        batch = {"s": d["observations"], "a": d["actions"], "r": d["rewards"], "ns": d["next_observations"],
+                 "d": d["terminals"]}
+        hyper = {"iql_tau": 0.8, "beta": 5.0, "discount": 0.97, "tau": 0.01, "deterministic": not gaussian}
+        lrs = {"v": 1e-3, "q": 2e-4, "pi": 5e-4}
+        tr = build(params, S, A, gaussian, hyper, lrs, None)
+        newp, newo, info = O.iql_step(params, O.new_opt_state(params), batch, hyper, lrs)
+        grads, lw = unflat(tr, tr.flat_gradient(to_tb(batch)))
+        for n, t in grads.items():
+            for k, g in t.items():
+                want = info["grads"][n][k]
+                assert np.max(np.abs(g - want)) <= 3e-5 * max(np.max(np.abs(want)), 1e-30), (B, n, k)
+        log = tr.train(to_tb(batch))
+        assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]],
+                      [info["value_loss"], info["q_loss"], info["actor_loss"]], 1e-5)
+        got = read_params(tr)
+        for n, t in got.items():
+            for k, p in t.items():
+                assert np.max(np.abs(p - newp[n][k])) <= 2e-6, (B, n, k)
+        assert tr.actor_lr_schedule is None
+
+
+def test_step_is_deterministic_and_batch_agnostic_to_padding():
+    """Bitwise run-to-run determinism (slab reductions, no float atomics) and no leakage from
+    a previous larger batch into a smaller one (rows >= B are masked)."""
+    build, _, _, read_params, to_tb, _ = _hip()
+    S, A = 17, 6
+    params = synth.synth_params(S, A, seed=5)
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    big = synth.synth_transitions(256, S, A, seed=6)
+    small = {k: v[:100].copy() for k, v in big.items()}
+    bb = {"s": big["observations"], "a": big["actions"], "r": big["rewards"], "ns": big["next_observations"],
+          "d": big["terminals"]}
+    sb = {"s": small["observations"], "a": small["actions"], "r": small["rewards"],
+          "ns": small["next_observations"], "d": small["terminals"]}
+    outs = []
+    for warm in (False, True):
+        tr = build(params, S, A, True, hyper, lrs, 1000)
+        if warm:
+            tr.flat_gradient(to_tb(bb))   # fills scratch rows 100..255 with other data
+        tr.train(to_tb(sb))
+        outs.append(read_params(tr))
+    for n in outs[0]:
+        for k in outs[0][n]:
+            assert np.array_equal(outs[0][n][k], outs[1][n][k]), (n, k)
+
+
+def test_error_behaviour_matches_reference():
+    import iql
+    build, _, _, _, to_tb, _ = _hip()
+    S, A = 17, 6
+    params = synth.synth_params(S, A, seed=5, gaussian=False)
+    tr = build(params, S, A, False, {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005},
+               {"v": 3e-4, "q": 3e-4, "pi": 3e-4}, 1000)
+    d = synth.synth_transitions(32, S, A, seed=6)
+    bad = [torch.from_numpy(d["observations"]).cuda(), torch.zeros(32, A + 1).cuda(),
+           torch.zeros(32, 1).cuda(), torch.from_numpy(d["next_observations"]).cuda(), torch.zeros(32, 1).cuda()]
+    with pytest.raises(RuntimeError, match="Actions shape missmatch"):
+        tr.train(bad)
+    buf = iql.ReplayBuffer(S, A, 16, "cuda")
+    with pytest.raises(ValueError, match="smaller than the dataset"):
+        buf.load_d4rl_dataset(d)
