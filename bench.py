@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — IQL gradient-steps/sec at batch=256 on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: draw 256 row indices
+(uniform with replacement), gather the rows from the HBM-resident replay buffer,
+7 MLP forwards, 3 losses, backward, Adam x3, Polyak.  Inputs are synthetic
+D4RL-shaped rows resident in HBM before the timed region starts.
+
+N = 1: BASELINE.json configs[1] (obs=17, act=6, 1M rows, batch=256): K steps replayed
+       as hipGraph chunks (ImplicitQLearning.train_steps).
+N > 1: configs[3]-style data parallelism at fixed per-GPU batch 256 (global batch 256*N,
+       weak scaling): per-rank device index draw, forward+backward, RCCL all-reduce of the
+       flat gradient, fused Adam/Polyak on every rank (ImplicitQLearning.train_on_buffer).
+       value = batch-256 gradient computations per second summed over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the round prompt) with `roofline` (the
+backward kernel, the step's dominant launch, against the fp32-MFMA peak) and, at N = 1,
+`cpu_baseline` (oracle/iql_torch_port.py — a PyTorch-CPU port of the reference step —
+timed on the host cores for a bounded ~20 s sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "jsrl-corl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+HID = 256
+
+
+def flops(S, A, B):
+    """Algorithmic FLOPs per launch: 2*M*N*K per GEMM, biases/elementwise excluded."""
+    def w(k0, d):
+        return k0 * HID + HID * HID + HID * d
+    wV, wQ, wP = w(S, 1), w(S + A, 1), w(S, A)
+    fwd = 2 * B * (2 * wV + 4 * wQ + wP)
+    bwd = 2 * B * ((2 * wV - S * HID) + 2 * (2 * wQ - (S + A) * HID) + (2 * wP - S * HID))
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--state-dim", type=int, default=17)
+    ap.add_argument("--action-dim", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as ge
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        ge.build()
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    ge._paths()
+    import iql
+    import synth
+
+    S, A, B = args.state_dim, args.action_dim, args.batch
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    # ---- synthetic HBM-resident buffer + nets (seed 0)
+    data = synth.synth_transitions(args.rows, S, A, seed=0)
+    buf = iql.ReplayBuffer(S, A, args.rows, dev)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        buf.load_d4rl_dataset(data)
+    del data
+    torch.manual_seed(0)
+    qf, vf, actor = iql.TwinQ(S, A).to(dev), iql.ValueFunction(S).to(dev), iql.GaussianPolicy(S, A, 1.0).to(dev)
+    tr = iql.ImplicitQLearning(
+        max_action=1.0, actor=actor, actor_optimizer=torch.optim.Adam(actor.parameters(), lr=3e-4),
+        q_network=qf, q_optimizer=torch.optim.Adam(qf.parameters(), lr=3e-4),
+        v_network=vf, v_optimizer=torch.optim.Adam(vf.parameters(), lr=3e-4),
+        iql_tau=0.7, beta=3.0, max_steps=1_000_000, discount=0.99, tau=0.005, device=dev)
+    if world > 1:
+        tr.enable_data_parallel()
+
+    def run(n):
+        if world > 1:
+            for _ in range(n):
+                tr.train_on_buffer(buf, B, seed=1234, sync=False)
+        else:
+            tr.train_steps(buf, n, B, seed=1234, return_losses=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity: the run trained (losses finite)
+    log = tr.train(buf.sample(B)) if world == 1 else tr.train_on_buffer(buf, B, seed=1, sync=True)
+    assert all(np.isfinite(v) for v in log.values()), log
+
+    # ---- roofline of the dominant kernel (backward), HIP events around each launch on the stream
+    f_fwd, f_bwd = flops(S, A, B)
+    roof = None
+    if world == 1:
+        tr.set_timing(True)
+        for _ in range(300):
+            tr.train_on_buffer(buf, B, seed=99, sync=False)
+        t_fwd, t_bwd, t_upd, t_tot = tr.get_timing_us()
+        tr.set_timing(False)
+        ach = f_bwd / (t_bwd * 1e-6) / 1e12
+        roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": f_bwd, "avg_launch_us": round(t_bwd, 3),
+                "event_us": {"fwd": round(t_fwd, 3), "bwd": round(t_bwd, 3), "update": round(t_upd, 3)},
+                "step_flops": f_fwd + f_bwd,
+                "step_frac_of_peak": round((f_fwd + f_bwd) * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = args.steps * world / dt
+    out = {
+        "metric": "IQL gradient-steps/sec at batch=256 (D4RL obs/act dims)",
+        "value": round(value, 1),
+        "unit": "steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"IQL step on synthetic buffer (obs={S}, act={A}, {args.rows} rows), batch={B} per GPU",
+                   "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "global_steps_per_s": round(args.steps / dt, 1)},
+    }
+    if roof:
+        out["roofline"] = roof
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import iql_torch_port as port
+        ncpu = os.cpu_count() or 1
+        sps1, n1, el1 = port.time_cpu_steps(S, A, B, min(args.rows, 200_000), seconds_budget=args.cpu_seconds, threads=1)
+        thr = min(ncpu, 16)
+        spsN, nN, elN = port.time_cpu_steps(S, A, B, min(args.rows, 200_000), seconds_budget=args.cpu_seconds, threads=thr)
+        best, cores = (sps1, 1) if sps1 >= spsN else (spsN, thr)
+        out["cpu_baseline"] = {
+            "value": round(best, 2), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"PyTorch-CPU port of the reference step (oracle/iql_torch_port.py), same S/A/B, 200k-row buffer: "
+                      f"{n1} steps in {el1:.1f}s @1 thread = {sps1:.1f}/s; {nN} steps in {elN:.1f}s @{thr} threads = {spsN:.1f}/s; "
+                      f"torch {torch.__version__}, {ncpu} host cpus"}
+        out["speedup_vs_cpu"] = round(value / best, 1)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

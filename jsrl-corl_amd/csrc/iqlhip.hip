@@ -57,11 +57,11 @@ struct iqlhip_ctx {
   int k_max = 0;
   int n_chunk_max = 0, n_rt_max = 0;
   size_t lds_fwd = 0, lds_bwd = 0;
-  // graph cache
+  // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
   hipStream_t cap_stream = nullptr;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t gexec = nullptr;
-  GraphKey gkey;
+  struct CachedGraph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; };
+  std::vector<CachedGraph> graphs;
+  unsigned long long graph_clock = 0;
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;         // 4 per recorded step
@@ -177,21 +177,23 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
 }
 
 static void drop_graph(iqlhip_ctx* c) {
-  if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-  if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
-  c->gkey = GraphKey();
+  for (auto& g : c->graphs) {
+    (void)hipGraphExecDestroy(g.exec);
+    (void)hipGraphDestroy(g.graph);
+  }
+  c->graphs.clear();
 }
 
 extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   if (!c) return IQLHIP_OK;
-  hipSetDevice(c->device);
-  hipDeviceSynchronize();
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
   drop_graph(c);
-  for (hipEvent_t e : c->ev) hipEventDestroy(e);
-  if (c->cap_stream) hipStreamDestroy(c->cap_stream);
-  hipFree(c->sc.h0); hipFree(c->sc.h1); hipFree(c->sc.heads); hipFree(c->sc.slab_a); hipFree(c->sc.slab_b);
-  hipFree(c->sc.loss_parts); hipFree(c->sc.losses); hipFree(c->flat_tmp); hipFree(c->loss_ring);
-  hipFree(c->idx_chunk); hipFree(c->sched); hipFree(c->hdr);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+  void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
+                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr};
+  for (void* b : bufs) (void)hipFree(b);
   delete c;
   return IQLHIP_OK;
 }
@@ -417,8 +419,17 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
   hipStream_t st = (hipStream_t)stream;
   GraphKey key;
   key.rows = rows_dev; key.ld = ld; key.B = B; key.K = K; key.params = c->params;
-  if (!(c->gexec && c->gkey == key)) {
-    drop_graph(c);
+  hipGraphExec_t gexec = nullptr;
+  for (auto& g : c->graphs)
+    if (g.key == key) { gexec = g.exec; g.stamp = ++c->graph_clock; }
+  if (!gexec) {
+    if (c->graphs.size() >= 4) {   // evict the least recently used
+      size_t lru = 0;
+      for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].stamp < c->graphs[lru].stamp) lru = i;
+      (void)hipGraphExecDestroy(c->graphs[lru].exec);
+      (void)hipGraphDestroy(c->graphs[lru].graph);
+      c->graphs.erase(c->graphs.begin() + lru);
+    }
     hipStream_t cs = c->cap_stream;
     HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     {
@@ -444,10 +455,11 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
       launch_bwd(c, p, cs);
       launch_upd(c, u, cs);
     }
-    hipError_t e = hipStreamEndCapture(cs, &c->graph);
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(cs, &graph);
     if (e != hipSuccess) return fail(IQLHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    HIPCHK(hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
-    c->gkey = key;
+    HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    c->graphs.push_back({key, graph, gexec, ++c->graph_clock});
   }
   unsigned long long hdr[4] = {(unsigned long long)size, (unsigned long long)seed, (unsigned long long)stream_offset, 0};
   HIPCHK(hipMemcpyAsync(c->hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
@@ -459,7 +471,7 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
     ev = &c->ev[c->ev_used];
     HIPCHK(hipEventRecord(ev[0], st));
   }
-  HIPCHK(hipGraphLaunch(c->gexec, st));
+  HIPCHK(hipGraphLaunch(gexec, st));
   if (ev) {
     HIPCHK(hipEventRecord(ev[1], st));
     HIPCHK(hipEventSynchronize(ev[1]));

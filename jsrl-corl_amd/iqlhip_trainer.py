@@ -312,18 +312,12 @@ class ImplicitQLearning:
         return b, keep, B
 
     # ------------------------------------------------------------------ the step
-    def train(self, batch: TensorBatch) -> Dict[str, float]:
-        """One IQL gradient step (iql.py:542-563).  Returns the three losses as floats
-        (one host sync instead of the reference's three .item() calls)."""
-        self._require_gpu()
-        b, keep, B = self._batch_struct(batch)
-        self._prepare(B)
+    def _run_step(self, b: "hb.Batch", B: int, sync: bool):
         self.total_it += 1
         for g in self._adam_t:
             self._adam_t[g] += 1
         sc = hb.StepScalars()
         lib = hb.lib()
-        out = (C.c_float * 3)()
         if self._dp_world > 1:
             self._fill_scalars(sc, self._adam_t, self._current_lrs(), 1.0 / (B * self._dp_world))
             flat = self._dp_flat()
@@ -334,40 +328,104 @@ class ImplicitQLearning:
             self._fill_scalars(sc, self._adam_t, self._current_lrs(), 1.0 / B)
             hb.check(lib.iqlhip_step(self._ctx, C.byref(b), C.byref(sc), self._stream()))
         self._step_schedule()
+        if not sync:
+            return None
+        out = (C.c_float * 3)()
         hb.check(lib.iqlhip_read_losses(self._ctx, out, self._stream()))
-        del keep
         return {"value_loss": float(out[0]), "q_loss": float(out[1]), "actor_loss": float(out[2])}
 
+    def train(self, batch: TensorBatch) -> Dict[str, float]:
+        """One IQL gradient step (iql.py:542-563).  Returns the three losses as floats
+        (one host sync instead of the reference's three .item() calls)."""
+        self._require_gpu()
+        b, keep, B = self._batch_struct(batch)
+        self._prepare(B)
+        log = self._run_step(b, B, sync=True)
+        del keep
+        return log
+
+    def _advance_schedule(self, k: int) -> np.ndarray:
+        """Actor learning rates USED by the next k steps; advances the CosineAnnealingLR object
+        by k steps.  Same float64 recursion as torch's CosineAnnealingLR.get_lr (eta_min = 0),
+        run as a plain loop instead of k scheduler.step() calls (~15 us each)."""
+        lr = float(self.actor_optimizer.param_groups[0]["lr"])
+        out = np.empty(k, dtype=np.float64)
+        sch = self.actor_lr_schedule
+        if sch is None:
+            out[:] = lr
+            return out
+        import math
+        T = sch.T_max
+        base = float(sch.base_lrs[0])
+        eta_min = float(sch.eta_min)
+        if eta_min != 0.0 or len(sch.base_lrs) != 1 or (sch._step_count == 1 and sch.last_epoch > 0):
+            for i in range(k):     # unusual scheduler state: let torch do it
+                out[i] = float(self.actor_optimizer.param_groups[0]["lr"])
+                self._step_schedule()
+            return out
+        e = sch.last_epoch
+        cos, pi = math.cos, math.pi
+        for i in range(k):
+            out[i] = lr
+            e += 1
+            if (e - 1 - T) % (2 * T) == 0:
+                lr = lr + base * (1 - cos(pi / T)) / 2
+            else:
+                lr = (1 + cos(pi * e / T)) / (1 + cos(pi * (e - 1) / T)) * lr
+        sch.last_epoch = e
+        sch._step_count += k
+        self.actor_optimizer.param_groups[0]["lr"] = lr
+        sch._last_lr = [lr]
+        self.actor_optimizer._opt_called = True
+        return out
+
+    def _scalar_table(self, k: int, inv_batch: float) -> np.ndarray:
+        """[k,12] float32 rows laid out like iqlhip_step_scalars for the next k steps."""
+        b1, b2, eps = self._adam_hyper()
+        lr_pi = self._advance_schedule(k)
+        lrs = self._current_lrs()
+        tab = np.empty((k, 12), dtype=np.float32)
+        steps = np.arange(1, k + 1, dtype=np.float64)
+        for i, g in enumerate(("v", "q", "pi")):
+            t = self._adam_t[g] + steps
+            lr = lr_pi if g == "pi" else lrs[g]
+            tab[:, i] = lr / (1.0 - np.power(b1, t))
+            tab[:, 3 + i] = np.sqrt(1.0 - np.power(b2, t))
+            self._adam_t[g] += k
+        tab[:, 6] = b2
+        tab[:, 7] = 1.0 - b1
+        tab[:, 8] = 1.0 - b2
+        tab[:, 9] = eps
+        tab[:, 10] = 1.0
+        tab[:, 11] = inv_batch
+        return tab
+
     def train_steps(self, replay_buffer, n_steps: int, batch_size: int, seed: int = 0,
-                    return_losses: bool = True) -> Optional[np.ndarray]:
+                    return_losses: bool = True, chunk: int = 1000) -> Optional[np.ndarray]:
         """n_steps consecutive `sample -> train` iterations without host round trips
         (the offline loop body, algorithms/offline/iql.py:631-635): indices are drawn on
         the device (uniform with replacement, Philox keyed by (seed, total_it)), the
-        steps replay as one hipGraph per chunk of <= 1024, per-step Adam / cosine-LR
-        scalars are precomputed on the host.  Returns losses [n_steps,3] (value,q,actor)."""
+        steps replay as one hipGraph per chunk of <= `chunk` (<= 1024), per-step Adam /
+        cosine-LR scalars are precomputed on the host.  Returns losses [n_steps,3]
+        (value, q, actor) when return_losses, else None (fully asynchronous)."""
         self._prepare(batch_size)
         if self._dp_world > 1:
-            raise NotImplementedError("train_steps is single-GPU; under data parallelism call train()")
+            raise NotImplementedError("train_steps is single-GPU; under data parallelism call train_on_buffer()")
         if not getattr(replay_buffer, "_gpu", False):
             raise ValueError("train_steps needs a ReplayBuffer that lives on the GPU")
         size = replay_buffer._index_bound()
         if size < 1:
             raise ValueError("replay buffer is empty")
+        chunk = max(1, min(int(chunk), K_MAX))
         lib = hb.lib()
         losses = np.empty((n_steps, 3), dtype=np.float32) if return_losses else None
         done = 0
         while done < n_steps:
-            k = min(K_MAX, n_steps - done)
-            arr = (hb.StepScalars * k)()
-            lrs = self._current_lrs()
-            for i in range(k):
-                for g in self._adam_t:
-                    self._adam_t[g] += 1
-                lrs["pi"] = float(self.actor_optimizer.param_groups[0]["lr"])
-                self._fill_scalars(arr[i], self._adam_t, lrs, 1.0 / batch_size)
-                self._step_schedule()
+            k = min(chunk, n_steps - done)
+            tab = self._scalar_table(k, 1.0 / batch_size)
             hb.check(lib.iqlhip_train_steps(
-                self._ctx, replay_buffer._rows.data_ptr(), replay_buffer._ld, size, batch_size, arr, k,
+                self._ctx, replay_buffer._rows.data_ptr(), replay_buffer._ld, size, batch_size,
+                tab.ctypes.data_as(C.POINTER(hb.StepScalars)), k,
                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(self.total_it) * ((batch_size + 1) // 2), self._stream()))
             self.total_it += k
             if return_losses:
@@ -376,6 +434,27 @@ class ImplicitQLearning:
                 losses[done: done + k] = np.frombuffer(buf, dtype=np.float32).reshape(k, 3)
             done += k
         return losses
+
+    def train_on_buffer(self, replay_buffer, batch_size: int, seed: int = 0, sync: bool = False):
+        """One step on rows drawn ON THE DEVICE from `replay_buffer` (no host index draw, no
+        host sync unless `sync`).  Data-parallel aware: each rank draws its own rows (seed is
+        offset by the rank), gradients are all-reduced before the update."""
+        self._prepare(batch_size)
+        size = replay_buffer._index_bound()
+        lib = hb.lib()
+        idx = getattr(self, "_idx_buf", None)
+        if idx is None or idx.numel() != batch_size:
+            idx = torch.empty(batch_size, dtype=torch.int64, device=self._dev)
+            self._idx_buf = idx
+        rank = torch.distributed.get_rank(self._dp_group) if self._dp_world > 1 else 0
+        hb.check(lib.iqlhip_draw_indices(idx.data_ptr(), batch_size, size, (int(seed) + 0x9E3779B97F4A7C15 * rank) & 0xFFFFFFFFFFFFFFFF,
+                                         int(self.total_it) * ((batch_size + 1) // 2), self._stream()))
+        S, A = self._S, self._A
+        base = replay_buffer._rows.data_ptr()
+        ld = replay_buffer._ld
+        b = hb.Batch(base, base + 4 * S, base + 4 * (2 * S + A), base + 4 * (S + A), base + 4 * (2 * S + A + 1),
+                     ld, ld, ld, ld, ld, idx.data_ptr(), batch_size)
+        return self._run_step(b, batch_size, sync)
 
     # ------------------------------------------------------------------ data parallel
     def enable_data_parallel(self, process_group=None) -> None:

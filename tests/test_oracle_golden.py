@@ -104,3 +104,23 @@ def test_fp64_oracle_brackets_reference():
     params, batch, hyper = single_step_inputs(meta)
     info = O.iql_losses_and_grads(params, batch, hyper, dtype=np.float64)
     assert_losses([info["value_loss"], info["q_loss"], info["actor_loss"]], z["losses"], 2e-6)
+
+
+@pytest.mark.parametrize("name", ["g1_S17A6_gauss_b3", "g1_S29A8_det_b10", "g7_edge_gauss"])
+def test_torch_port_matches_reference(name):
+    """The PyTorch-CPU port used as bench.py's cpu_baseline reproduces the reference's losses."""
+    import torch
+    from oracle import iql_torch_port as port
+    z, meta = load_golden(name)
+    params, batch, hyper = single_step_inputs(meta)
+    torch.set_num_threads(1)
+    tr = port.CpuIQL(meta["S"], meta["A"], params=params, gaussian=meta["gaussian"], iql_tau=hyper["iql_tau"],
+                     beta=hyper["beta"], discount=hyper["discount"], tau=hyper["tau"], lrs=meta["lrs"],
+                     max_steps=meta["max_steps"])
+    tb = [torch.from_numpy(batch["s"]), torch.from_numpy(batch["a"]), torch.from_numpy(batch["r"][:, None].copy()),
+          torch.from_numpy(batch["ns"]), torch.from_numpy(batch["d"][:, None].copy())]
+    log = tr.train(tb)
+    assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"], 1e-6)
+    want = z["param.q1.w1"]
+    got = sub(tr.qf.q1.net[2].weight.detach().numpy(), meta["stride"])
+    assert np.max(np.abs(got - want)) <= 1e-7
