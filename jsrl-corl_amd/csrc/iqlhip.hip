@@ -54,6 +54,7 @@ struct iqlhip_ctx {
   long long* idx_chunk = nullptr;     // [K_max * max_batch]
   iqlhip_step_scalars* sched = nullptr;  // [K_max]
   unsigned long long* hdr = nullptr;  // {size, seed, offset}
+  unsigned long long* stamps = nullptr;  // diagnostic builds (-DIQL_STAMPS): [4096 blocks][16]
   int k_max = 0;
   int n_chunk_max = 0, n_rt_max = 0;
   size_t lds_fwd = 0, lds_bwd = 0;
@@ -162,6 +163,10 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   HIPCHK(hipMalloc((void**)&c->sched, (size_t)c->k_max * sizeof(iqlhip_step_scalars)));
   HIPCHK(hipMalloc((void**)&c->hdr, 4 * sizeof(unsigned long long)));
   HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+#ifdef IQL_STAMPS
+  HIPCHK(hipMalloc((void**)&c->stamps, 4096 * 16 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->stamps, 0, 4096 * 16 * sizeof(unsigned long long)));
+#endif
   // LDS sizes
   const int kq = dims->state_dim + dims->action_dim;
   c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * xld_host(kq)) * sizeof(float);
@@ -192,7 +197,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
-                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr};
+                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
   return IQLHIP_OK;
@@ -231,6 +236,7 @@ static int check_batch(const iqlhip_ctx* c, const iqlhip_batch* b) {
 
 static StepParams make_step(const iqlhip_ctx* c, const iqlhip_batch* b, float inv_batch) {
   StepParams p;
+  p.stamps = c->stamps;
   p.L = c->L;
   p.hy = c->hyper;
   p.params = c->params;
@@ -523,6 +529,10 @@ extern "C" int iqlhip_debug_read(iqlhip_ctx* c, const char* name, float* host_ou
   else if (!strcmp(name, "h1")) { src = c->sc.h1; n = (int64_t)4 * MB * HID; }
   else if (!strcmp(name, "heads")) { src = c->sc.heads; n = (int64_t)6 * NSPLIT * MB + (int64_t)NSPLIT * MB * c->dims.action_dim; }
   else if (!strcmp(name, "loss_parts")) { src = c->sc.loss_parts; n = 4 * 64; }
+  else if (!strcmp(name, "stamps")) {   // 64-bit stamps returned as pairs of 32-bit words
+    if (!c->stamps) return fail(IQLHIP_EINVAL, "library built without -DIQL_STAMPS");
+    src = (const float*)c->stamps; n = 4096 * 16 * 2;
+  }
   else if (!strcmp(name, "grads")) {
     // flatten the slabs of the LAST forward_backward/step with the batch size implied by max_batch slabs in use
     return fail(IQLHIP_EINVAL, "use iqlhip_forward_backward to obtain the flat gradient");

@@ -49,7 +49,30 @@ struct DevScratch {
   int max_batch;
 };
 
+// Diagnostic build only (-DIQL_STAMPS): lane 0 of every block writes s_memtime at phase
+// boundaries to a buffer of its own; no product path reads it.
+#ifdef IQL_STAMPS
+__device__ __forceinline__ unsigned long long iql_memtime() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(p, i)                                                                        \
+  do {                                                                                     \
+    const unsigned long long t_ = iql_memtime();                                           \
+    if ((p).stamps && threadIdx.x == 0) {                                                  \
+      (p).stamps[(long long)blockIdx.x * 16 + (i)] = t_;                                   \
+      if ((i) == 0) (p).stamps[(long long)blockIdx.x * 16 + 15] = wall_clock64();          \
+    }                                                                                      \
+  } while (0)
+#else
+#define STAMP(p, i) do {} while (0)
+#endif
+
 struct StepParams {
+  unsigned long long* stamps;
   iqlhip_layout L;
   iqlhip_hyper hy;
   const float* params;
@@ -140,6 +163,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   float* H1s = H0s + RT_ROWS * H0_LD;        // [32][T64_LD]
   float* Xs = H1s + RT_ROWS * T64_LD;        // [32][xld]
 
+  STAMP(p, 0);
   // ---- prefetch this wave's W1 rows (16 output units x 256 k) as MFMA B fragments
   const int n1 = ns * 64 + wave * 16 + l15;  // hidden-1 unit of this lane
   f32x4 bw[16];
@@ -148,6 +172,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 
   gather_rows(p, kind, row0, k0, xld, Xs);
   __syncthreads();
+  STAMP(p, 1);
 
   // ---- layer 0: this wave computes H0[32][64*wave .. +64)
   {
@@ -194,6 +219,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     }
   }
   __syncthreads();
+  STAMP(p, 2);
 
   // save H0 columns [64*ns, +64) of the trainable instances for the backward pass
   if (slot >= 0) {
@@ -231,6 +257,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     }
   }
   __syncthreads();
+  STAMP(p, 3);
 
   {
     const int rl = tid >> 3;
@@ -263,6 +290,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       }
     }
   }
+  STAMP(p, 4);
 }
 
 // ---------------------------------------------------------------------------
@@ -377,6 +405,10 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   const float* H0g = p.sc.h0 + (long long)net * MB * HID;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef IQL_STAMPS
+  if (p.stamps) p.stamps += 2048 * 16;   // second half of the stamp buffer: the forward kernel owns the first
+#endif
+  STAMP(p, 0);
 
   if (local < n_a) {
     // ===================== (a): dW1[j-tile][i-tile] over one 256-row chunk =====================
@@ -418,6 +450,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       }
     }
     __syncthreads();
+    STAMP(p, 1);
     if (designated) {
       // db2[dd] = sum_r dY[r][dd];  dlog_std[dd] = sum_r w (1 - diff^2/var) * inv_batch (inside clamp range only)
       for (int dd = wave; dd < D; dd += 4) {
@@ -440,6 +473,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       }
     }
 
+    STAMP(p, 2);
     // ---- main loop: this wave reduces rows [cbase + 64*wave, +64)
     f32x4 acc[2][4];
 #pragma unroll
@@ -506,6 +540,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = MFMA16(av[ta], bb[ks][tb], acc[ta][tb]);
     }
 
+    STAMP(p, 3);
     // ---- cross-wave reduction of the 32x64 tile through LDS, then coalesced store
     {
       float* myred = red + wave * 32 * T64_LD;
@@ -567,6 +602,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         else slab[nl.w2 + (long long)(rr - 1) * HID + j0 + jj] = s;
       }
     }
+    STAMP(p, 4);
     return;
   }
 
@@ -604,6 +640,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       if (row < B) row_loss_grad(p, net, row, dyrow, nullptr, la, lbv);
     }
     __syncthreads();
+    STAMP(p, 5);
 
     // dH1s[r][j] = (sum_dd dY[r][dd] W2[dd][j]) * (H1[r][j] > 0)
 #pragma unroll
@@ -624,6 +661,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
     }
     __syncthreads();
+    STAMP(p, 6);
 
     // dH0 partial over this wave's 64 j's: [32 rows][64 cols]
     {
@@ -654,6 +692,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         }
     }
     __syncthreads();
+    STAMP(p, 7);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int f = tid + 256 * q;
@@ -670,6 +709,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     }
     __syncthreads();
 
+    STAMP(p, 8);
     float* slabB = p.sc.slab_b + p.sc.slab_b_off[net] + (long long)rt * (HID * k0 + HID);
     // dW0[i][kc] partial = sum_r dH0[r][i] X[r][kc];  this wave: i in [i0 + 16*wave, +16)
     {
@@ -710,6 +750,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int rl = 0; rl < RT_ROWS; ++rl) s += dH0s[rl * T64_LD + tid];
       slabB[(long long)HID * k0 + i0 + tid] = s;
     }
+    STAMP(p, 9);
   }
 }
 

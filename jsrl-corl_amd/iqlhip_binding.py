@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiqlhip.so")
+LIB_PATH = os.environ.get("IQLHIP_LIB", os.path.join(_HERE, "libiqlhip.so"))  # IQLHIP_LIB: diagnostic builds
 
 IQLHIP_HIDDEN = 256
 NET_V, NET_Q1, NET_Q2, NET_PI = 0, 1, 2, 3

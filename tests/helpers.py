@@ -111,10 +111,22 @@ def check_step_against_golden(z, meta, info, newp, newo, *, grad_rtol=1e-5, para
                     continue
                 want = z[key]
                 got = sub(p, stride).reshape(want.shape)
-                e = float(np.max(np.abs(got.astype(np.float64) - want)))
-                worst[key] = e
+                diff = np.abs(got.astype(np.float64) - want)
                 atol = target_atol if net in ("qt1", "qt2") else param_atol
-                assert e <= atol, f"{key}: abs err {e} > {atol}"
+                tol = np.full(diff.shape, atol)
+                gkey = f"grad.{net}.{t}"
+                if gkey in z and net not in ("qt1", "qt2"):
+                    # Adam's first step is u(g) = -lr*g/(|g|+eps): an element whose gradient is
+                    # within fp32 summation noise (dg ~ 2e-6*|g|_inf) of eps=1e-8 legitimately moves
+                    # by up to lr*eps*dg/(|g|+eps)^2 (<= lr) more.  Everything else holds param_atol.
+                    g = np.abs(z[gkey].astype(np.float64)).reshape(diff.shape)
+                    dg = 2e-6 * max(float(g.max()), 1e-30)
+                    lr = max(meta["lrs"].values())
+                    tol = tol + lr * np.minimum(1.0, 1e-8 * dg / (g + 1e-8) ** 2)
+                e = float(np.max(diff))
+                worst[key] = e
+                bad = diff > tol
+                assert not bad.any(), f"{key}: {int(bad.sum())} elements beyond tolerance, worst abs err {e}"
     if newo is not None and check_moments:
         for mv in ("m", "v"):
             for net, tensors in newo[mv].items():

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the forward / backward kernels from in-kernel s_memtime stamps.
+Needs the diagnostic library:  IQLHIP_LIB=jsrl-corl_amd/libiqlhip_stamps.so python tools/gpu_stamps.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "jsrl-corl_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import contextlib
+import io
+
+import numpy as np
+import torch
+
+import iql
+import synth
+
+S, A, B = int(os.environ.get("S", 17)), int(os.environ.get("A", 6)), int(os.environ.get("B", 256))
+N = 1_000_000
+buf = iql.ReplayBuffer(S, A, N, "cuda")
+with contextlib.redirect_stdout(io.StringIO()):
+    buf.load_d4rl_dataset(synth.synth_transitions(N, S, A, seed=0))
+qf, vf, actor = iql.TwinQ(S, A).cuda(), iql.ValueFunction(S).cuda(), iql.GaussianPolicy(S, A, 1.0).cuda()
+tr = iql.ImplicitQLearning(1.0, actor, torch.optim.Adam(actor.parameters(), lr=3e-4), qf,
+                           torch.optim.Adam(qf.parameters(), lr=3e-4), vf, torch.optim.Adam(vf.parameters(), lr=3e-4),
+                           max_steps=1000000, device="cuda")
+for it in range(50):
+    tr.train_on_buffer(buf, B, seed=7)
+torch.cuda.synchronize()
+raw = tr.debug_read("stamps")
+st = raw.view(np.uint64).reshape(4096, 16)
+
+
+def report(name, blocks, labels, sel=None):
+    blk = st[blocks]
+    blk = blk[blk[:, 0] > 0]
+    if sel is not None:
+        blk = blk[sel(blk)]
+    if len(blk) == 0:
+        print(name, "no blocks")
+        return
+    t0 = blk[:, 0].astype(np.int64)
+    first = t0.min()
+    print(f"{name}: {len(blk)} blocks; start skew (cycles) median {np.median(t0 - first):.0f} max {np.max(t0 - first)}")
+    prev = 0
+    for i, lab in labels:
+        d = blk[:, i].astype(np.int64) - blk[:, prev].astype(np.int64)
+        ok = blk[:, i] > 0
+        if ok.sum() == 0:
+            continue
+        print(f"   {lab:28s} median {np.median(d[ok]):8.0f}  p90 {np.percentile(d[ok], 90):8.0f}  max {d[ok].max():8d} cycles")
+        prev = i
+    last = max(i for i, _ in labels)
+    tot = blk[:, last].astype(np.int64) - t0
+    print(f"   {'block total':28s} median {np.median(tot):8.0f}  max {tot.max():8d};  kernel span {int((blk[:, last].astype(np.int64)).max() - first)} cycles")
+
+
+n_rt = (B + 31) // 32
+fwd_blocks = np.arange(8 * n_rt * 4)
+report("fwd", fwd_blocks, [(1, "prefetch+gather"), (2, "layer0"), (3, "H0 save + layer1"), (4, "H1 save + head")])
+n_chunk = (B + 255) // 256
+per_net = 32 * n_chunk + 4 * n_rt
+nb = 8 * ((per_net + 1) // 2)
+bw = 2048 + np.arange(nb)
+ids = np.arange(nb)
+local = (ids >> 3) * 2 + ((ids & 7) >> 2)
+a_blocks = bw[local < 32 * n_chunk]
+b_blocks = bw[(local >= 32 * n_chunk) & (local < per_net)]
+report("bwd (a) dW1 tiles", a_blocks, [(1, "dY prologue (256 rows)"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
+                                        (4, "reduce + store (+extras)")])
+report("bwd (b) dH0/dW0", b_blocks, [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"),
+                                      (8, "reduce+mask"), (9, "dW0 MFMA + stores")])
+# clock estimate: cycles per 100 MHz tick over the fwd kernel
+blk = st[fwd_blocks]
+blk = blk[blk[:, 0] > 0]
+print("stamp[15] (realtime) range", int(blk[:, 15].max() - blk[:, 15].min()), "ticks of 10ns vs cycles", int(blk[:, 0].max() - blk[:, 0].min()))
