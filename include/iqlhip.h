@@ -174,6 +174,10 @@ int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed
  * "grads" (flat summed gradient, n_params), "loss_parts". */
 int iqlhip_debug_read(iqlhip_ctx* ctx, const char* name, float* host_out, int64_t max_floats, int64_t* n_out,
                       void* stream);
+/* Micro-benchmark hook: `repeat` back-to-back launches of one kernel of the step (0 fwd, 1 bwd,
+ * 2 update with zero step size, 3 all three); average microseconds per launch.  Synchronous. */
+int iqlhip_debug_time_kernel(iqlhip_ctx* ctx, const iqlhip_batch* batch, int which, int repeat, float* avg_us,
+                             void* stream);
 /* Average device time (microseconds) of the kernels of the last iqlhip_step /
  * train_steps call measured with hipEvents on `stream`; 0 when timing is off. */
 int iqlhip_set_timing(iqlhip_ctx* ctx, int enabled);

@@ -49,6 +49,8 @@ struct iqlhip_ctx {
   // scratch (library-owned)
   DevScratch sc{};
   float* flat_tmp = nullptr;          // n_params + 4 (debug "grads")
+  float* xb = nullptr;                // compact batch [max_batch][row_ld]: rows [s | a | s' | r | d | pad]
+  int64_t row_ld = 0;
   float* loss_ring = nullptr;         // [ring_cap][4]
   int ring_cap = 0;
   long long* idx_chunk = nullptr;     // [K_max * max_batch]
@@ -145,7 +147,9 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   };
   HIPCHK(dalloc(&c->sc.h0, (size_t)4 * MB * HID));
   HIPCHK(dalloc(&c->sc.h1, (size_t)4 * MB * HID));
-  HIPCHK(dalloc(&c->sc.heads, (size_t)6 * NSPLIT * MB + (size_t)NSPLIT * MB * A));
+  HIPCHK(dalloc(&c->sc.heads, (size_t)MB * HEAD_LD + (size_t)NSPLIT * MB * A));
+  c->row_ld = iqlhip_row_stride(dims->state_dim, A);
+  HIPCHK(dalloc(&c->xb, (size_t)MB * c->row_ld));
   HIPCHK(dalloc(&c->sc.slab_a, (size_t)c->n_chunk_max * c->L.n_params));
   size_t sb = 0;
   for (int n = 0; n < 4; ++n) {
@@ -169,11 +173,14 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
 #endif
   // LDS sizes
   const int kq = dims->state_dim + dims->action_dim;
-  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * xld_host(kq)) * sizeof(float);
+  const int ks_ = dims->state_dim;   // V / pi layer-0 width; Q nets use kq
+  const int w0_lds_k = (kq <= W0_LDS_MAX_K) ? kq : ((ks_ <= W0_LDS_MAX_K) ? ks_ : 0);
+  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * 132 + IQLHIP_MAX_ACTION * 65 + 16 +
+                        HID * w0_lds_k) * sizeof(float);
   const int dyld = ((A + 15) & ~15) + 1;
   const size_t lds_a = (size_t)(4 * 32 * T64_LD + 2 * CHUNK_ROWS * dyld + 32 * 32 + 64) * sizeof(float);
-  const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 33 +
-                                RT_ROWS * xld_host(kq)) * sizeof(float);
+  const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 33 + 4 +
+                                RT_ROWS * 132) * sizeof(float);
   c->lds_bwd = std::max(lds_a, lds_b);
   HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd));
   HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
@@ -197,7 +204,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
-                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps};
+                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
   return IQLHIP_OK;
@@ -234,22 +241,79 @@ static int check_batch(const iqlhip_ctx* c, const iqlhip_batch* b) {
   return IQLHIP_OK;
 }
 
-static StepParams make_step(const iqlhip_ctx* c, const iqlhip_batch* b, float inv_batch) {
+// An indexed batch must be row-addressed storage in the packed layout (what ReplayBuffer holds).
+static int check_indexed(const iqlhip_ctx* c, const iqlhip_batch* b) {
+  const int S = c->dims.state_dim, A = c->dims.action_dim;
+  const bool packed = b->ld_s == c->row_ld && b->ld_a == c->row_ld && b->ld_r == c->row_ld && b->ld_ns == c->row_ld &&
+                      b->ld_d == c->row_ld && b->a_dev == b->s_dev + S && b->ns_dev == b->s_dev + S + A &&
+                      b->r_dev == b->s_dev + 2 * S + A && b->d_dev == b->s_dev + 2 * S + A + 1;
+  if (!packed) return fail(IQLHIP_EINVAL, "indexed batches must address packed rows [s|a|s'|r|d] with ld=%lld",
+                           (long long)c->row_ld);
+  if (((uintptr_t)b->s_dev) & 15) return fail(IQLHIP_EINVAL, "packed rows must be 16-byte aligned");
+  return IQLHIP_OK;
+}
+
+static void launch_gather(const iqlhip_ctx* c, const float* rows, const long long* idx, int n, hipStream_t st) {
+  const int total = n * (int)(c->row_ld / 4);
+  hipLaunchKernelGGL(iql_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, st, rows, (long long)c->row_ld, idx,
+                     c->xb, n);
+}
+
+// Bring the caller's batch into the packed staging buffer xb (the kernels read nothing else).
+static int stage_batch(const iqlhip_ctx* c, const iqlhip_batch* b, hipStream_t st) {
+  if (b->idx_dev) {
+    int rc = check_indexed(c, b);
+    if (rc) return rc;
+    launch_gather(c, b->s_dev, (const long long*)b->idx_dev, b->rows, st);
+  } else {
+    const int total = b->rows * (int)c->row_ld;
+    hipLaunchKernelGGL(iql_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, c->xb, (int)c->row_ld,
+                       c->dims.state_dim, c->dims.action_dim, b->rows, b->s_dev, (long long)b->ld_s, b->a_dev,
+                       (long long)b->ld_a, b->r_dev, (long long)b->ld_r, b->ns_dev, (long long)b->ld_ns, b->d_dev,
+                       (long long)b->ld_d);
+  }
+  return IQLHIP_OK;
+}
+
+static NetPtrs net_ptrs(const iqlhip_net_layout& nl, const float* base) {
+  NetPtrs n;
+  n.w0 = base + nl.w0; n.b0 = base + nl.b0; n.w1 = base + nl.w1; n.b1 = base + nl.b1;
+  n.w2 = base + nl.w2; n.b2 = base + nl.b2; n.k0 = nl.k_in; n.d = nl.d_out;
+  return n;
+}
+
+static StepParams make_step(const iqlhip_ctx* c, int rows, float inv_batch) {
   StepParams p;
+  memset(&p, 0, sizeof p);
   p.stamps = c->stamps;
-  p.L = c->L;
+  const iqlhip_layout& L = c->L;
+  const float* tb = c->target - L.target_src;
+  const int S = c->dims.state_dim, A = c->dims.action_dim;
+  // instances: V(s'), V(s), Qt1, Qt2, Q1, Q2, pi
+  p.inst[0] = net_ptrs(L.net[IQLHIP_NET_V], c->params);  p.xoff[0] = S + A; p.slot[0] = -1;
+  p.inst[1] = net_ptrs(L.net[IQLHIP_NET_V], c->params);  p.xoff[1] = 0;     p.slot[1] = 0;
+  p.inst[2] = net_ptrs(L.net[IQLHIP_NET_Q1], tb);        p.xoff[2] = 0;     p.slot[2] = -1;
+  p.inst[3] = net_ptrs(L.net[IQLHIP_NET_Q2], tb);        p.xoff[3] = 0;     p.slot[3] = -1;
+  p.inst[4] = net_ptrs(L.net[IQLHIP_NET_Q1], c->params); p.xoff[4] = 0;     p.slot[4] = 1;
+  p.inst[5] = net_ptrs(L.net[IQLHIP_NET_Q2], c->params); p.xoff[5] = 0;     p.slot[5] = 2;
+  p.inst[6] = net_ptrs(L.net[IQLHIP_NET_PI], c->params); p.xoff[6] = 0;     p.slot[6] = 3;
+  p.inst[7] = p.inst[6]; p.xoff[7] = 0; p.slot[7] = -1;
+  for (int n = 0; n < 4; ++n) {
+    p.net[n] = net_ptrs(L.net[n], c->params);
+    p.go[n].w1 = L.net[n].w1; p.go[n].b1 = L.net[n].b1; p.go[n].w2 = L.net[n].w2; p.go[n].b2 = L.net[n].b2;
+    p.go[n].log_std = L.net[n].log_std;
+  }
+  p.log_std = (L.net[IQLHIP_NET_PI].log_std >= 0) ? c->params + L.net[IQLHIP_NET_PI].log_std : nullptr;
   p.hy = c->hyper;
-  p.params = c->params;
-  p.target = c->target;
   p.sc = c->sc;
-  p.b.s = b->s_dev; p.b.a = b->a_dev; p.b.r = b->r_dev; p.b.ns = b->ns_dev; p.b.d = b->d_dev;
-  p.b.ld_s = b->ld_s; p.b.ld_a = b->ld_a; p.b.ld_r = b->ld_r; p.b.ld_ns = b->ld_ns; p.b.ld_d = b->ld_d;
-  p.b.idx = (const long long*)b->idx_dev;
-  p.b.rows = b->rows;
-  p.S = c->dims.state_dim;
-  p.A = c->dims.action_dim;
+  p.xb = c->xb;
+  p.ld = (int)c->row_ld;
+  p.rows = rows;
+  p.S = S;
+  p.A = A;
   p.policy = c->dims.policy;
   p.inv_batch = inv_batch;
+  p.n_params = L.n_params;
   return p;
 }
 
@@ -272,22 +336,26 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.batch_rows = rows;
   u.sched = nullptr;
   u.sched_idx = 0;
+  u.n_upd_blocks = (int)((c->L.n_params / 4 + 255) / 256);
+  u.g_rows = nullptr; u.g_ld = c->row_ld; u.g_idx = nullptr; u.g_xb = c->xb; u.g_n = 0;
   return u;
 }
 
 static void launch_fwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
-  const int n_rt = (p.b.rows + RT_ROWS - 1) / RT_ROWS;
+  const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   hipLaunchKernelGGL(iql_fwd_kernel, dim3(8 * n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
 }
 static void launch_bwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
-  const int n_rt = (p.b.rows + RT_ROWS - 1) / RT_ROWS;
-  const int n_chunk = (p.b.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
+  const int n_chunk = (p.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
   const int per_net = 32 * n_chunk + 4 * n_rt;
   hipLaunchKernelGGL(iql_bwd_kernel, dim3(8 * ((per_net + 1) / 2)), dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
 }
 static void launch_upd(const iqlhip_ctx* c, const UpdParams& u, hipStream_t st) {
-  const int nb = (int)((c->L.n_params / 4 + 255) / 256);
-  hipLaunchKernelGGL(iql_update_kernel, dim3(nb), dim3(256), 0, st, u);
+  int nb = u.n_upd_blocks;
+  if (u.g_idx) nb += (u.g_n * (int)(u.g_ld / 4) + 255) / 256;   // gather blocks for the next step's rows
+  if (u.sched) hipLaunchKernelGGL(iql_update_kernel<true>, dim3(nb), dim3(256), 0, st, u);
+  else hipLaunchKernelGGL(iql_update_kernel<false>, dim3(nb), dim3(256), 0, st, u);
 }
 
 static int ensure_events(iqlhip_ctx* c, int n) {
@@ -335,7 +403,9 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   int rc = check_batch(c, b);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  StepParams p = make_step(c, b, sc->inv_batch);
+  rc = stage_batch(c, b, st);
+  if (rc) return rc;
+  StepParams p = make_step(c, b->rows, sc->inv_batch);
   UpdParams u = make_upd(c, sc, b->rows, nullptr);
   hipEvent_t* ev = nullptr;
   if (c->timing) {
@@ -362,7 +432,9 @@ extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, con
   int rc = check_batch(c, b);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  StepParams p = make_step(c, b, sc->inv_batch);
+  rc = stage_batch(c, b, st);
+  if (rc) return rc;
+  StepParams p = make_step(c, b->rows, sc->inv_batch);
   UpdParams u = make_upd(c, sc, b->rows, nullptr);
   launch_fwd(c, p, st);
   launch_bwd(c, p, st);
@@ -421,7 +493,8 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
   if (B < 1 || B > c->dims.max_batch) return fail(IQLHIP_EINVAL, "batch_rows outside [1,max_batch]");
   if (size < 1) return fail(IQLHIP_EINVAL, "empty buffer");
   const int S = c->dims.state_dim, A = c->dims.action_dim;
-  if (ld < 2 * S + A + 2) return fail(IQLHIP_EINVAL, "row stride too small");
+  if (ld != c->row_ld) return fail(IQLHIP_EINVAL, "row stride must be iqlhip_row_stride(S,A)=%lld", (long long)c->row_ld);
+  if (((uintptr_t)rows_dev) & 15) return fail(IQLHIP_EINVAL, "packed rows must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   GraphKey key;
   key.rows = rows_dev; key.ld = ld; key.B = B; key.K = K; key.params = c->params;
@@ -444,19 +517,15 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
       hipLaunchKernelGGL(iql_draw_indices_kernel, dim3(nb), dim3(256), 0, cs, c->idx_chunk, n, (long long)size,
                          0ull, 0ull, (const unsigned long long*)c->hdr);
     }
+    launch_gather(c, rows_dev, c->idx_chunk, B, cs);   // rows of step 0; step k+1's ride on update k
     for (int k = 0; k < K; ++k) {
-      iqlhip_batch b;
-      b.s_dev = rows_dev; b.a_dev = rows_dev + S; b.ns_dev = rows_dev + S + A;
-      b.r_dev = rows_dev + 2 * S + A; b.d_dev = rows_dev + 2 * S + A + 1;
-      b.ld_s = b.ld_a = b.ld_r = b.ld_ns = b.ld_d = ld;
-      b.idx_dev = (const int64_t*)(c->idx_chunk + (long long)k * B);
-      b.rows = B;
-      StepParams p = make_step(c, &b, sc[0].inv_batch);
+      StepParams p = make_step(c, B, sc[0].inv_batch);
       UpdParams u = make_upd(c, &sc[0], B, nullptr);
       u.sched = c->sched;
       u.sched_idx = k;
       u.loss_ring = c->loss_ring;
       u.ring_slot = k;
+      if (k + 1 < K) { u.g_rows = rows_dev; u.g_idx = c->idx_chunk + (long long)(k + 1) * B; u.g_n = B; }
       launch_fwd(c, p, cs);
       launch_bwd(c, p, cs);
       launch_upd(c, u, cs);
@@ -518,6 +587,45 @@ extern "C" int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t S, 
 }
 
 // ---------------------------------------------------------------------------
+// Micro-benchmark hook: launch ONE kernel of the step `repeat` times back to back and return the
+// average time per launch (hipEvents on `stream`).  which: 0 fwd, 1 bwd, 2 update (no-op scalars:
+// step_size 0, so parameters do not move), 3 fwd+bwd+update.  Synchronous.
+extern "C" int iqlhip_debug_time_kernel(iqlhip_ctx* c, const iqlhip_batch* b, int which, int repeat, float* avg_us,
+                                        void* stream) {
+  if (!c || !avg_us || repeat < 1) return fail(IQLHIP_EINVAL, "bad argument");
+  int rc = check_batch(c, b);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  rc = stage_batch(c, b, st);
+  if (rc) return rc;
+  iqlhip_step_scalars sc;
+  memset(&sc, 0, sizeof sc);
+  sc.bc2_sqrt[0] = sc.bc2_sqrt[1] = sc.bc2_sqrt[2] = 1.f;
+  sc.beta2 = 1.f; sc.eps = 1e-8f; sc.grad_scale = 1.f; sc.inv_batch = 1.f / b->rows;
+  StepParams p = make_step(c, b->rows, sc.inv_batch);
+  UpdParams u = make_upd(c, &sc, b->rows, nullptr);
+  u.tau = 0.f; u.one_minus_tau = 1.f;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) { launch_fwd(c, p, st); launch_bwd(c, p, st); }
+  HIPCHK(hipEventRecord(e0, st));
+  for (int i = 0; i < repeat; ++i) {
+    if (which == 0 || which == 3) launch_fwd(c, p, st);
+    if (which == 1 || which == 3) launch_bwd(c, p, st);
+    if (which == 2 || which == 3) launch_upd(c, u, st);
+  }
+  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *avg_us = ms * 1e3f / repeat;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return IQLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 extern "C" int iqlhip_debug_read(iqlhip_ctx* c, const char* name, float* host_out, int64_t max_floats, int64_t* n_out,
                                  void* stream) {
   if (!c || !name || !host_out) return fail(IQLHIP_EINVAL, "NULL argument");
@@ -527,7 +635,7 @@ extern "C" int iqlhip_debug_read(iqlhip_ctx* c, const char* name, float* host_ou
   const int MB = c->dims.max_batch;
   if (!strcmp(name, "h0")) { src = c->sc.h0; n = (int64_t)4 * MB * HID; }
   else if (!strcmp(name, "h1")) { src = c->sc.h1; n = (int64_t)4 * MB * HID; }
-  else if (!strcmp(name, "heads")) { src = c->sc.heads; n = (int64_t)6 * NSPLIT * MB + (int64_t)NSPLIT * MB * c->dims.action_dim; }
+  else if (!strcmp(name, "heads")) { src = c->sc.heads; n = (int64_t)MB * HEAD_LD + (int64_t)NSPLIT * MB * c->dims.action_dim; }
   else if (!strcmp(name, "loss_parts")) { src = c->sc.loss_parts; n = 4 * 64; }
   else if (!strcmp(name, "stamps")) {   // 64-bit stamps returned as pairs of 32-bit words
     if (!c->stamps) return fail(IQLHIP_EINVAL, "library built without -DIQL_STAMPS");

@@ -4,15 +4,19 @@
 //   iql_fwd_kernel     7 MLP instances x row-tiles(32 rows) x 4 column slices
 //   iql_bwd_kernel     (a) dW1 tiles over a 256-row chunk, (b) dH0/dW0 per row-tile
 //   iql_update_kernel  slab-sum of gradients + Adam (3 lr groups) + Polyak + losses
+//                      (+ extra blocks that gather the NEXT step's rows into the compact batch)
+//
+// The step is latency-bound at B=256 (0.54 GFLOP against ~20 dependent memory
+// round trips), so every kernel is written as: issue ALL global loads of the
+// block first -> one wait -> LDS staging -> MFMA phases fed from LDS/registers.
 //
 // All GEMMs use v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).  Lane maps
 // (wave64, l = lane, l15 = l&15, g = l>>4):
 //   A operand: A[m=l15][k=g]      B operand: B[k=g][n=l15]
 //   C/D:       D[m=4g+reg][n=l15] (reg = 0..3)
-// "float4-along-k" trick: a lane loads 4 consecutive k of its row once and
-// feeds element t to the t-th of 4 MFMAs — A and B use the same (g,t)->k map,
-// so the 4 MFMAs cover 16 k exactly once.  "float4-along-n" trick: a lane
-// loads 4 consecutive output columns and MFMA t produces columns {4n+t}.
+// "float4-along-k": a lane loads 4 consecutive k of its row once and feeds element t to
+// the t-th of 4 MFMAs — A and B use the same (g,t)->k map, so 4 MFMAs cover 16 k once.
+// "float4-along-n": a lane loads 4 consecutive output columns; MFMA t produces columns {4n+t}.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,23 +31,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define H0_LD 260           // LDS row stride of a [rows][256] tile (16-B aligned, bank-shifted)
 #define T64_LD 68           // LDS row stride of a [rows][64] tile
 #define NSPLIT 4            // column slices of the hidden layer per row tile
+#define HEAD_LD 24          // scalar head partials per row: [inst 0..5][ns 0..3]
+#define W0_LDS_MAX_K 64     // layer-0 weights are staged in LDS when k_in <= this (64 KiB)
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-struct DevBatch {
-  const float *s, *a, *r, *ns, *d;
-  long long ld_s, ld_a, ld_r, ld_ns, ld_d;
-  const long long* idx;   // nullable
-  int rows;
-};
 
 struct DevScratch {
   float* h0;        // [4][max_batch][256]  post-ReLU layer-0 activations of V(s),Q1,Q2,pi
   float* h1;        // [4][max_batch][256]
-  float* heads;     // scalar instances: [6][NSPLIT][max_batch]; pi: [NSPLIT][max_batch][A] after that
+  float* heads;     // [max_batch][HEAD_LD] scalar partials (bias folded into slice 0), then pi: [max_batch][A][NSPLIT]
   float* slab_a;    // [n_chunk_max][n_params]  chunk slabs: w1,b1,w2,b2,log_std grads
   float* slab_b;    // per net [n_rt_max][256*k_in+256]  row-tile slabs: w0,b0 grads
-  float* loss_parts;// [4][n_chunk_max]: value, q1, q2(err^2 sums), actor
+  float* loss_parts;// [4][64]: value, q1, q2 (err^2 sums), actor — per chunk
   float* losses;    // [4]
   long long slab_b_off[4];  // float offset of net's region in slab_b
   int max_batch;
@@ -62,70 +61,53 @@ __device__ __forceinline__ unsigned long long iql_memtime() {
 #define STAMP(p, i)                                                                        \
   do {                                                                                     \
     const unsigned long long t_ = iql_memtime();                                           \
-    if ((p).stamps && threadIdx.x == 0) {                                                  \
-      (p).stamps[(long long)blockIdx.x * 16 + (i)] = t_;                                   \
-      if ((i) == 0) (p).stamps[(long long)blockIdx.x * 16 + 15] = wall_clock64();          \
-    }                                                                                      \
+    if ((p).stamps && threadIdx.x == 0) (p).stamps[(long long)blockIdx.x * 16 + (i)] = t_; \
   } while (0)
 #else
 #define STAMP(p, i) do {} while (0)
 #endif
 
-struct StepParams {
-  unsigned long long* stamps;
-  iqlhip_layout L;
-  iqlhip_hyper hy;
-  const float* params;
-  const float* target;
-  DevScratch sc;
-  DevBatch b;
-  int S, A, policy;
-  float inv_batch;
+// Direct pointers of one MLP (host-built, so a block needs ONE scalar-load round to find its weights).
+struct NetPtrs {
+  const float *w0, *b0, *w1, *b1, *w2, *b2;
+  int k0, d;
+};
+// Offsets of one net's gradient tensors inside a chunk slab (= arena layout).
+struct NetGrad {
+  long long w1, b1, w2, b2, log_std;
 };
 
+// The batch is ALWAYS the packed staging buffer xb: rows [s(S) | a(A) | s'(S) | r | d | pad], stride ld.
+struct StepParams {
+  unsigned long long* stamps;
+  NetPtrs inst[8];     // forward instances 0..6: V(s'), V(s), Qt1, Qt2, Q1, Q2, pi
+  int xoff[8];         // first column of the instance's input inside a packed row (0 or S+A)
+  int slot[8];         // activation slot (0..3) of trainable instances, -1 otherwise
+  NetPtrs net[4];      // trainable nets V, Q1, Q2, pi (backward)
+  NetGrad go[4];
+  const float* log_std;   // Gaussian policy log_std (A floats) or nullptr
+  iqlhip_hyper hy;
+  DevScratch sc;
+  const float* xb;
+  int ld, rows;
+  int S, A, policy;
+  float inv_batch;
+  long long n_params;
+};
+
+// Force kernel-argument fields into SGPRs NOW.  hipcc sinks each s_load next to its first use, which
+// turns one scalar-cache miss (~1k cycles at kernel start) into 3-5 dependent ones; an empty asm that
+// "uses" the values makes the compiler issue all the loads in one batch behind a single wait.
+#define PIN_S(x) asm volatile("" ::"s"(x))
+#define PIN_P(x) asm volatile("" ::"s"((unsigned long long)(uintptr_t)(x)))
+
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int xld_for(int k0p) { return ((k0p + 29) / 32) * 32 + 2; }
+#define XR_MAX_F4 5          // float4 per thread to cover a 32-row packed tile: ceil(32*132/4/256)
 
-// instance -> (net layout index, uses target arena, input kind, activation slot)
-// input kind: 0 = s, 1 = s', 2 = [s|a]
-__device__ __forceinline__ void inst_info(int inst, int& net, bool& tgt, int& kind, int& slot) {
-  switch (inst) {
-    case 0: net = IQLHIP_NET_V;  tgt = false; kind = 1; slot = -1; break;  // V(s')
-    case 1: net = IQLHIP_NET_V;  tgt = false; kind = 0; slot = 0;  break;  // V(s)
-    case 2: net = IQLHIP_NET_Q1; tgt = true;  kind = 2; slot = -1; break;  // Qt1
-    case 3: net = IQLHIP_NET_Q2; tgt = true;  kind = 2; slot = -1; break;  // Qt2
-    case 4: net = IQLHIP_NET_Q1; tgt = false; kind = 2; slot = 1;  break;  // Q1
-    case 5: net = IQLHIP_NET_Q2; tgt = false; kind = 2; slot = 2;  break;  // Q2
-    default: net = IQLHIP_NET_PI; tgt = false; kind = 0; slot = 3; break;  // pi
-  }
-}
-
-__device__ __forceinline__ const float* net_base(const StepParams& p, bool tgt) {
-  return tgt ? (p.target - p.L.target_src) : p.params;
-}
-
-__device__ __forceinline__ long long src_row(const DevBatch& b, int r) {
-  return b.idx ? b.idx[r] : (long long)r;
-}
-
-// Gather RT_ROWS input rows of `kind` into Xs[32][xld] (zero padded).
-__device__ __forceinline__ void gather_rows(const StepParams& p, int kind, int row0, int k0, int xld, float* Xs) {
-  const int tid = threadIdx.x;
-  const int rl = tid >> 3;
-  const int row = row0 + rl;
-  const bool valid = row < p.b.rows;
-  const long long j = valid ? src_row(p.b, row) : 0;
-  const float* base0;
-  long long ld0;
-  if (kind == 1) { base0 = p.b.ns; ld0 = p.b.ld_ns; } else { base0 = p.b.s; ld0 = p.b.ld_s; }
-  const float* r0 = base0 + j * ld0;
-  const float* r1 = p.b.a + j * p.b.ld_a;
-  const int S = p.S;
-  for (int c = (tid & 7); c < xld; c += 8) {
-    float v = 0.f;
-    if (valid && c < k0) v = (c < S) ? r0[c] : r1[c - S];
-    Xs[rl * xld + c] = v;
-  }
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_base) {
+  // 64 lanes x 16 B: global (per-lane address) -> LDS (wave-uniform base + lane*16), no VGPR staging
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -143,38 +125,107 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
 
-  int net, kind, slot;
-  bool tgt;
-  inst_info(inst, net, tgt, kind, slot);
-  const iqlhip_net_layout& nl = p.L.net[net];
-  const float* base = net_base(p, tgt);
-  const float* w0 = base + nl.w0;
-  const float* b0 = base + nl.b0;
-  const float* w1 = base + nl.w1;
-  const float* b1 = base + nl.b1;
-  const float* w2 = base + nl.w2;
-  const int k0 = nl.k_in;
+  const NetPtrs np = p.inst[inst];
+  const int xoff = p.xoff[inst];
+  const int slot = p.slot[inst];
+  const int k0 = np.k0;
   const int k0p = (k0 + 3) & ~3;
-  const int xld = xld_for(k0p);
-  const int D = nl.d_out;
+  const int D = np.d;
+  const int ld = p.ld;
+  const int B = p.rows;
+  const bool w0_lds = (k0 <= W0_LDS_MAX_K);
+  const float* xb = p.xb;
+  float* h0g = p.sc.h0;
+  float* h1g = p.sc.h1;
+  float* headsg = p.sc.heads;
+  const int MB = p.sc.max_batch;
+  const int Aact = p.A;
+  PIN_P(np.w0); PIN_P(np.b0); PIN_P(np.w1); PIN_P(np.b1); PIN_P(np.w2); PIN_P(np.b2);
+  PIN_S(k0); PIN_S(D); PIN_S(xoff); PIN_S(slot); PIN_S(ld); PIN_S(B); PIN_S(MB); PIN_S(Aact);
+  PIN_P(xb); PIN_P(h0g); PIN_P(h1g); PIN_P(headsg);
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* H0s = smem;                         // [32][H0_LD]
   float* H1s = H0s + RT_ROWS * H0_LD;        // [32][T64_LD]
-  float* Xs = H1s + RT_ROWS * T64_LD;        // [32][xld]
+  float* Xr = H1s + RT_ROWS * T64_LD;        // [32][ld]  packed rows of this tile
+  float* W2s = Xr + RT_ROWS * 132;           // [D][64] head weights of this column slice, then b2[D]
+  float* W0s = W2s + IQLHIP_MAX_ACTION * 65;   // [256*k0] flat copy of layer-0 weights (when w0_lds); 16-B aligned
+  // (no integer casts on LDS pointers: they would demote every access to a flat load, and a flat load
+  //  waits vmcnt(0) — it would drain the W1 stream that is meant to stay in flight under layer 0)
 
   STAMP(p, 0);
-  // ---- prefetch this wave's W1 rows (16 output units x 256 k) as MFMA B fragments
+  // ======== issue every global load of the block.  vmcnt retires in issue order: the small operands of
+  // layer 0 go first, the 64 KiB W1 slice last — it keeps streaming while layer 0 runs (no LDS-DMA
+  // here: a DMA in flight would make __syncthreads() wait vmcnt(0), i.e. for W1 as well).
+  // (a) the 32 packed input rows, contiguous in xb: n_x float4, clamped at the end of the batch
+  const int n_x = RT_ROWS * ld / 4;
+  const int x_last = B * ld / 4 - 1;
+  f32x4 xr[XR_MAX_F4];
+#pragma unroll
+  for (int q = 0; q < XR_MAX_F4; ++q) {
+    const int f = min(row0 * ld / 4 + min(tid + 256 * q, n_x - 1), x_last);
+    xr[q] = *(const f32x4*)(xb + 4 * f);
+  }
+  // (b) head weights of this slice + b2, biases
+  f32x4 w2pre[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = min(tid + 256 * q, D * 16 - 1);
+    w2pre[q] = *(const f32x4*)(np.w2 + (e >> 4) * HID + ns * 64 + 4 * (e & 15));
+  }
+  const float b2v = np.b2[min(tid, D - 1)];
+  f32x4 bias0[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) bias0[ct] = *(const f32x4*)(np.b0 + wave * 64 + ct * 16 + 4 * g);
+  const f32x4 bias1 = *(const f32x4*)(np.b1 + ns * 64 + wave * 16 + 4 * g);
+  // (c) layer-0 weights: flat float4 copy of 64*k0 float4 (thread handles tid + 256 j); 8 loads cover k0 <= 32
+  const int n_w0v = 64 * k0;
+  f32x4 w0v[16];
+  if (w0_lds) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w0v[j] = *(const f32x4*)(np.w0 + 4 * min(tid + 256 * j, n_w0v - 1));
+    if (k0 > 32) {
+#pragma unroll
+      for (int j = 8; j < 16; ++j) w0v[j] = *(const f32x4*)(np.w0 + 4 * min(tid + 256 * j, n_w0v - 1));
+    }
+  }
+  // (d) this wave's W1 rows (16 output units x 256 k) as MFMA fragments: 64 KiB per block
   const int n1 = ns * 64 + wave * 16 + l15;  // hidden-1 unit of this lane
   f32x4 bw[16];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(w1 + (long long)n1 * HID + 16 * ks + 4 * g);
+  for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + n1 * HID + 16 * ks + 4 * g);
 
-  gather_rows(p, kind, row0, k0, xld, Xs);
+#pragma unroll
+  for (int q = 0; q < XR_MAX_F4; ++q) {
+    const int f = tid + 256 * q;
+    if (f < n_x) *(f32x4*)(Xr + 4 * f) = xr[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = tid + 256 * q;
+    if (e < D * 16) *(f32x4*)(W2s + 4 * e) = w2pre[q];
+  }
+  if (tid < D) W2s[D * 64 + tid] = b2v;
+  if (w0_lds) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = tid + 256 * j;
+      if (f < n_w0v) *(f32x4*)(W0s + 4 * f) = w0v[j];
+    }
+    if (k0 > 32) {
+#pragma unroll
+      for (int j = 8; j < 16; ++j) {
+        const int f = tid + 256 * j;
+        if (f < n_w0v) *(f32x4*)(W0s + 4 * f) = w0v[j];
+      }
+    }
+  }
   __syncthreads();
   STAMP(p, 1);
 
-  // ---- layer 0: this wave computes H0[32][64*wave .. +64)
+  // ---- layer 0: this wave computes H0[32][64*wave .. +64).  Operand roles: A = W0 (m = hidden unit),
+  // B = X (n = row), so a lane's 4 accumulator registers are 4 consecutive hidden units of ONE row:
+  // one ds_write_b128 into the row-major H0 tile.
   {
     f32x4 acc[2][4];
 #pragma unroll
@@ -182,40 +233,93 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nks = k0p >> 2;
-    const float* wrow[4];
+    const float* x0 = Xr + l15 * ld + xoff;
+    const float* x1 = Xr + (16 + l15) * ld + xoff;
+    float bcur[4], bnxt[4], acur[2], anxt[2];
+    if (w0_lds && nks <= 8) {
+      // all operands of the (<= 8) k-steps are read up front, then the MFMAs run back to back
+      const float* wl[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) wrow[ct] = w0 + (long long)(wave * 64 + ct * 16 + l15) * k0;
-    float bcur[4], bnxt[4];
-    {
-      const int k = g;
+      for (int ct = 0; ct < 4; ++ct) wl[ct] = W0s + (wave * 64 + ct * 16 + l15) * k0;
+      float bq[8][4], aq[8][2];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) bcur[ct] = (k < k0) ? wrow[ct][k] : 0.f;
-    }
-    for (int ks = 0; ks < nks; ++ks) {
-      const int kn = 4 * (ks + 1) + g;
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = 4 * ks + g;
+        const int kc = min(kk, k0 - 1);
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) bnxt[ct] = (kn < k0) ? wrow[ct][kn] : 0.f;
-      const float a0 = Xs[l15 * xld + 4 * ks + g];
-      const float a1 = Xs[(16 + l15) * xld + 4 * ks + g];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        acc[0][ct] = MFMA16(a0, bcur[ct], acc[0][ct]);
-        acc[1][ct] = MFMA16(a1, bcur[ct], acc[1][ct]);
+        for (int ct = 0; ct < 4; ++ct) { const float v = wl[ct][kc]; bq[ks][ct] = (kk < k0) ? v : 0.f; }
+        aq[ks][0] = x0[kc];
+        aq[ks][1] = x1[kc];
       }
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) bcur[ct] = bnxt[ct];
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks < nks) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            acc[0][ct] = MFMA16(bq[ks][ct], aq[ks][0], acc[0][ct]);
+            acc[1][ct] = MFMA16(bq[ks][ct], aq[ks][1], acc[1][ct]);
+          }
+        }
+      }
+    } else if (w0_lds) {
+      const float* wl[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) wl[ct] = W0s + (wave * 64 + ct * 16 + l15) * k0;
+      {
+        const int kc = min(g, k0 - 1);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { const float v = wl[ct][kc]; bcur[ct] = (g < k0) ? v : 0.f; }
+        acur[0] = x0[kc];
+        acur[1] = x1[kc];
+      }
+      for (int ks = 0; ks < nks; ++ks) {
+        const int kn = 4 * (ks + 1) + g;       // operands of the next k-step (read while this one's MFMAs run)
+        const int kc = min(kn, k0 - 1);        // X columns >= k0 hold other fields: W0 = 0 there
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { const float v = wl[ct][kc]; bnxt[ct] = (kn < k0) ? v : 0.f; }
+        anxt[0] = x0[kc];
+        anxt[1] = x1[kc];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          acc[0][ct] = MFMA16(bcur[ct], acur[0], acc[0][ct]);
+          acc[1][ct] = MFMA16(bcur[ct], acur[1], acc[1][ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) bcur[ct] = bnxt[ct];
+        acur[0] = anxt[0];
+        acur[1] = anxt[1];
+      }
+    } else {
+      const float* wrow[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) wrow[ct] = np.w0 + (wave * 64 + ct * 16 + l15) * k0;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) { const float v = wrow[ct][min(g, k0 - 1)]; bcur[ct] = (g < k0) ? v : 0.f; }
+      for (int ks = 0; ks < nks; ++ks) {
+        const int kn = 4 * (ks + 1) + g;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { const float v = wrow[ct][min(kn, k0 - 1)]; bnxt[ct] = (kn < k0) ? v : 0.f; }
+        const int kc = min(4 * ks + g, k0 - 1);
+        const float a0 = x0[kc];
+        const float a1 = x1[kc];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          acc[0][ct] = MFMA16(bcur[ct], a0, acc[0][ct]);
+          acc[1][ct] = MFMA16(bcur[ct], a1, acc[1][ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) bcur[ct] = bnxt[ct];
+      }
     }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      const int n = wave * 64 + ct * 16 + l15;
-      const float bias = b0[n];
 #pragma unroll
-      for (int rtile = 0; rtile < 2; ++rtile)
+      for (int rtile = 0; rtile < 2; ++rtile) {
+        f32x4 h;
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float h = fmaxf(acc[rtile][ct][reg] + bias, 0.f);
-          H0s[(rtile * 16 + 4 * g + reg) * H0_LD + n] = h;
-        }
+        for (int reg = 0; reg < 4; ++reg) h[reg] = fmaxf(acc[rtile][ct][reg] + bias0[ct][reg], 0.f);
+        *(f32x4*)(H0s + (rtile * 16 + l15) * H0_LD + wave * 64 + ct * 16 + 4 * g) = h;
+      }
     }
   }
   __syncthreads();
@@ -223,19 +327,19 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 
   // save H0 columns [64*ns, +64) of the trainable instances for the backward pass
   if (slot >= 0) {
-    float* dst = p.sc.h0 + (long long)slot * p.sc.max_batch * HID;
+    float* dst = h0g + slot * MB * HID;
     const int rl = tid >> 3;
     const int row = row0 + rl;
-    if (row < p.b.rows) {
+    if (row < B) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = ns * 64 + 4 * ((tid & 7) + 8 * j);
-        *(f32x4*)(dst + (long long)row * HID + col) = *(const f32x4*)(H0s + rl * H0_LD + col);
+        *(f32x4*)(dst + row * HID + col) = *(const f32x4*)(H0s + rl * H0_LD + col);
       }
     }
   }
 
-  // ---- layer 1: this wave computes H1[32][n1 tile of 16]
+  // ---- layer 1: this wave computes H1[32][16 units]; A = W1 fragments (m = unit), B = H0 (n = row)
   {
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -244,17 +348,18 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       const f32x4 a1 = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 16 * ks + 4 * g);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc0 = MFMA16(a0[t], bw[ks][t], acc0);
-        acc1 = MFMA16(a1[t], bw[ks][t], acc1);
+        acc0 = MFMA16(bw[ks][t], a0[t], acc0);
+        acc1 = MFMA16(bw[ks][t], a1[t], acc1);
       }
     }
-    const float bias = b1[n1];
-    const int cl = wave * 16 + l15;
+    f32x4 h0, h1;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      H1s[(4 * g + reg) * T64_LD + cl] = fmaxf(acc0[reg] + bias, 0.f);
-      H1s[(16 + 4 * g + reg) * T64_LD + cl] = fmaxf(acc1[reg] + bias, 0.f);
+      h0[reg] = fmaxf(acc0[reg] + bias1[reg], 0.f);
+      h1[reg] = fmaxf(acc1[reg] + bias1[reg], 0.f);
     }
+    *(f32x4*)(H1s + l15 * T64_LD + wave * 16 + 4 * g) = h0;
+    *(f32x4*)(H1s + (16 + l15) * T64_LD + wave * 16 + 4 * g) = h1;
   }
   __syncthreads();
   STAMP(p, 3);
@@ -263,18 +368,17 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     const int rl = tid >> 3;
     const int row = row0 + rl;
     const int sub = tid & 7;
-    if (slot >= 0 && row < p.b.rows) {
-      float* dst = p.sc.h1 + (long long)slot * p.sc.max_batch * HID;
+    if (slot >= 0 && row < B) {
+      float* dst = h1g + slot * MB * HID;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int cl = 4 * (sub + 8 * j);
-        *(f32x4*)(dst + (long long)row * HID + ns * 64 + cl) = *(const f32x4*)(H1s + rl * T64_LD + cl);
+        *(f32x4*)(dst + row * HID + ns * 64 + cl) = *(const f32x4*)(H1s + rl * T64_LD + cl);
       }
     }
-    // ---- head partial sums over this block's 64 hidden-1 units
-    const int MB = p.sc.max_batch;
+    // ---- head partial sums over this block's 64 hidden-1 units (slice 0 also adds the bias)
     for (int dd = 0; dd < D; ++dd) {
-      const float* w2r = w2 + (long long)dd * HID + ns * 64;
+      const float* w2r = W2s + dd * 64;
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -284,9 +388,10 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       acc += __shfl_xor(acc, 1);
       acc += __shfl_xor(acc, 2);
       acc += __shfl_xor(acc, 4);
-      if (sub == 0 && row < p.b.rows) {
-        if (inst < 6) p.sc.heads[((long long)inst * NSPLIT + ns) * MB + row] = acc;
-        else p.sc.heads[(long long)6 * NSPLIT * MB + ((long long)ns * MB + row) * p.A + dd] = acc;
+      if (ns == 0) acc += W2s[D * 64 + dd];
+      if (sub == 0 && row < B) {
+        if (inst < 6) headsg[row * HEAD_LD + inst * NSPLIT + ns] = acc;
+        else headsg[MB * HEAD_LD + (row * Aact + dd) * NSPLIT + ns] = acc;
       }
     }
   }
@@ -294,34 +399,57 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// Head values (sum of the 4 column-slice partials in fixed order + bias).
-__device__ __forceinline__ float head_scalar(const StepParams& p, int inst, int row, float bias) {
-  const int MB = p.sc.max_batch;
-  const float* h = p.sc.heads + (long long)inst * NSPLIT * MB + row;
-  return ((h[0] + h[MB]) + h[2 * MB]) + h[3 * (long long)MB] + bias;
-}
-__device__ __forceinline__ float head_pi(const StepParams& p, int row, int dd, float bias) {
-  const int MB = p.sc.max_batch;
-  const float* h = p.sc.heads + (long long)6 * NSPLIT * MB + (long long)row * p.A + dd;
-  const long long st = (long long)MB * p.A;
-  return ((h[0] + h[st]) + h[2 * st]) + h[3 * st] + bias;
+// Loss gradients at the heads.  The per-row inputs are loaded first (RowIn, issue
+// only) so that the caller can overlap them with its other loads; row_finish does
+// the arithmetic.  Head = sum of the 4 column-slice partials in fixed order
+// (the bias is already inside slice 0).
+struct RowIn {
+  f32x4 h[6];       // scalar head partials: inst 0..5 x ns 0..3
+  float r, d;
+};
+
+__device__ __forceinline__ void row_issue(const StepParams& p, int row, RowIn& in) {
+  const f32x4* h = (const f32x4*)(p.sc.heads + row * HEAD_LD);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) in.h[i] = h[i];
+  const float* xr = p.xb + row * p.ld + 2 * p.S + p.A;
+  in.r = xr[0];
+  in.d = xr[1];
 }
 
-// Per-row loss terms and dL/d(head pre-activation) for `net`.
-//   dy[0..D) written to dyrow (stride 1); returns the row's loss term(s):
-//   V: w*u^2      Q1: e1^2 (lossB = e2^2)     pi: w*bc
-// For the Gaussian policy dls[dd] receives w*(1 - diff^2/var) (d/dlog_std terms).
-__device__ __forceinline__ void row_loss_grad(const StepParams& p, int net, int row, float* dyrow, float* dlsrow,
-                                              float& lossA, float& lossB) {
+__device__ __forceinline__ float sum4(const f32x4 v) { return ((v[0] + v[1]) + v[2]) + v[3]; }
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1): one expf and one division (absolute error ~1 ulp of 1.0; saturates
+// correctly: exp -> inf gives 1, exp -> 0 gives -1).
+__device__ __forceinline__ float tanh_via_exp(float x) { return 1.f - 2.f / (expf(2.f * x) + 1.f); }
+
+// dL/d(head pre-activation) of `net` for one row -> dyrow[0..D); loss terms:
+//   V: lossA = w*u^2     Q1/Q2: lossA = e1^2, lossB = e2^2     pi: lossA = w*bc
+// For the Gaussian policy dlsrow[dd] (if non-null) receives w*(1 - diff^2/var).
+// Per-action-dim constants of the Gaussian policy (clamped log_std, 1/var): lane dd holds dim dd's.
+// Must be called with ALL lanes of the wave active (row_finish reads them with a lane broadcast).
+struct PiConst { float ls, ivar; };
+__device__ __forceinline__ PiConst pi_consts(const StepParams& p, int net) {
+  PiConst c;
+  c.ls = 0.f;
+  c.ivar = 1.f;
+  if (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) {
+    const float lsr = p.log_std[min((int)(threadIdx.x & 63), p.A - 1)];
+    c.ls = fminf(fmaxf(lsr, p.hy.log_std_min), p.hy.log_std_max);
+    const float sig = expf(c.ls);
+    c.ivar = 1.f / (sig * sig);
+  }
+  return c;
+}
+
+__device__ __forceinline__ void row_finish(const StepParams& p, int net, int row, const RowIn& in, const PiConst pc,
+                                           float* dyrow, float* dlsrow, float& lossA, float& lossB) {
   const float invB = p.inv_batch;
   lossA = 0.f;
   lossB = 0.f;
-  const float bV = p.params[p.L.net[IQLHIP_NET_V].b2];
   if (net == IQLHIP_NET_V || net == IQLHIP_NET_PI) {
-    const float bt1 = (p.target - p.L.target_src)[p.L.net[IQLHIP_NET_Q1].b2];
-    const float bt2 = (p.target - p.L.target_src)[p.L.net[IQLHIP_NET_Q2].b2];
-    const float tq = fminf(head_scalar(p, 2, row, bt1), head_scalar(p, 3, row, bt2));
-    const float v = head_scalar(p, 1, row, bV);
+    const float tq = fminf(sum4(in.h[2]), sum4(in.h[3]));
+    const float v = sum4(in.h[1]);
     const float u = tq - v;
     if (net == IQLHIP_NET_V) {
       const float wgt = fabsf(p.hy.iql_tau - ((u < 0.f) ? 1.f : 0.f));
@@ -329,43 +457,53 @@ __device__ __forceinline__ void row_loss_grad(const StepParams& p, int net, int 
       dyrow[0] = (-2.f * wgt * u) * invB;
       return;
     }
-    // policy
     const float w = fminf(expf(p.hy.beta * u), p.hy.exp_adv_max);
-    const iqlhip_net_layout& nl = p.L.net[IQLHIP_NET_PI];
     const int A = p.A;
-    const DevBatch& b = p.b;
-    const float* arow = b.a + src_row(b, row) * b.ld_a;
+    const float* arow = p.xb + row * p.ld + p.S;
+    const f32x4* hp = (const f32x4*)(p.sc.heads + p.sc.max_batch * HEAD_LD + row * A * NSPLIT);
     float bc = 0.f;
-    for (int dd = 0; dd < A; ++dd) {
-      const float mu = tanhf(head_pi(p, row, dd, p.params[nl.b2 + dd]));
-      const float diff = arow[dd] - mu;
-      float dmu;
-      if (p.policy == IQLHIP_POLICY_GAUSSIAN) {
-        const float lsr = p.params[nl.log_std + dd];
-        const float ls = fminf(fmaxf(lsr, p.hy.log_std_min), p.hy.log_std_max);
-        const float sig = expf(ls);
-        const float var = sig * sig;
-        bc += diff * diff / (2.f * var) + ls + 0.918938533204672742f;  // log(sqrt(2 pi))
-        dmu = (-(w * diff) / var) * invB;
-        if (dlsrow) dlsrow[dd] = w * (1.f - diff * diff / var);
-      } else {
-        bc += diff * diff;
-        dmu = (-2.f * w * diff) * invB;
+    const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
+    // per-action-dim constants (pc) are the same for every row: lane dd holds dim dd's; they are read with
+    // v_readlane (uniform dd), which ignores EXEC, so partially active waves (ragged batch) are fine.
+    for (int d0 = 0; d0 < A; d0 += 8) {
+      // batch the loads of 8 action dims (unconditional, clamped), then do the arithmetic
+      f32x4 hv[8];
+      float acv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int dd = min(d0 + j, A - 1);
+        hv[j] = hp[dd];
+        acv[j] = arow[dd];
       }
-      dyrow[dd] = dmu * (1.f - mu * mu);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int dd = d0 + j;
+        if (dd < A) {
+          const float mu = tanh_via_exp(sum4(hv[j]));
+          const float diff = acv[j] - mu;
+          float dmu;
+          if (gauss) {
+            const float ls = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pc.ls), dd));
+            const float ivar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pc.ivar), dd));
+            const float q = diff * diff * ivar;
+            bc += 0.5f * q + ls + 0.918938533204672742f;  // log(sqrt(2 pi))
+            dmu = (-(w * diff) * ivar) * invB;
+            if (dlsrow) dlsrow[dd] = w * (1.f - q);
+          } else {
+            bc += diff * diff;
+            dmu = (-2.f * w * diff) * invB;
+          }
+          dyrow[dd] = dmu * (1.f - mu * mu);
+        }
+      }
     }
     lossA = w * bc;
     return;
   }
-  // Q nets
-  const DevBatch& b = p.b;
-  const long long j = src_row(b, row);
-  const float r = b.r[j * b.ld_r];
-  const float d = b.d[j * b.ld_d];
-  const float nv = head_scalar(p, 0, row, bV);
-  const float y = r + ((1.f - d) * p.hy.discount) * nv;
-  const float e1 = head_scalar(p, 4, row, p.params[p.L.net[IQLHIP_NET_Q1].b2]) - y;
-  const float e2 = head_scalar(p, 5, row, p.params[p.L.net[IQLHIP_NET_Q2].b2]) - y;
+  const float nv = sum4(in.h[0]);
+  const float y = in.r + ((1.f - in.d) * p.hy.discount) * nv;
+  const float e1 = sum4(in.h[4]) - y;
+  const float e2 = sum4(in.h[5]) - y;
   lossA = e1 * e1;
   lossB = e2 * e2;
   dyrow[0] = ((net == IQLHIP_NET_Q1) ? e1 : e2) * invB;
@@ -390,19 +528,30 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   const int net = x & 3;
   const int local = (bid >> 3) * 2 + (x >> 2);
   const int n_a = 32 * n_chunk;
-  if (local >= n_a + 4 * n_rt) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int B = p.b.rows;
+  const int B = p.rows;
   const int MB = p.sc.max_batch;
 
-  const iqlhip_net_layout& nl = p.L.net[net];
-  const int D = nl.d_out;
+  const NetPtrs np = p.net[net];
+  const NetGrad go = p.go[net];
+  const int D = np.d;
   const int Dp = (D + 15) & ~15;      // 16 or 32
   const int DYLD = Dp + 1;
-  const float* w2 = p.params + nl.w2;
-  const float* H1g = p.sc.h1 + (long long)net * MB * HID;
-  const float* H0g = p.sc.h0 + (long long)net * MB * HID;
+  const float* w2 = np.w2;
+  const float* H1g = p.sc.h1 + net * MB * HID;
+  const float* H0g = p.sc.h0 + net * MB * HID;
+  {
+    const float* xb_ = p.xb; const float* hd_ = p.sc.heads; float* sa_ = p.sc.slab_a; float* sb_ = p.sc.slab_b;
+    const int ld_ = p.ld, S_ = p.S, A_ = p.A, pol_ = p.policy, k0_ = np.k0;
+    const long long sbo_ = p.sc.slab_b_off[net], npar_ = p.n_params;
+    PIN_P(np.w1); PIN_P(np.w2); PIN_P(H1g); PIN_P(H0g); PIN_P(xb_); PIN_P(hd_); PIN_P(sa_); PIN_P(sb_);
+    PIN_S(D); PIN_S(B); PIN_S(MB); PIN_S(ld_); PIN_S(S_); PIN_S(A_); PIN_S(pol_); PIN_S(k0_);
+    PIN_S(sbo_); PIN_S(npar_); PIN_S(go.w1); PIN_S(go.b1); PIN_S(go.w2); PIN_S(go.b2); PIN_S(go.log_std);
+    PIN_S(p.inv_batch); PIN_S(p.hy.iql_tau); PIN_S(p.hy.beta); PIN_S(p.hy.discount); PIN_S(p.hy.exp_adv_max);
+    PIN_S(n_chunk); PIN_S(n_rt);
+  }
+  if (local >= n_a + 4 * n_rt) return;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef IQL_STAMPS
@@ -423,23 +572,48 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     float* W2s = dLs + CHUNK_ROWS * DYLD;            // [D][32]
     float* rsm = W2s + 32 * 32;                      // [64] small reductions
     const bool designated = (jt == 0 && it == 0);
-    float* slab = p.sc.slab_a + (long long)c * p.L.n_params;
+    const bool extras = (it == 0);
+    float* slab = p.sc.slab_a + (long long)c * p.n_params;
 
-    // ---- prologue: dY for the 256 rows of the chunk (thread = row)
+    // ---- loads, in the order they are needed (vmcnt retires in issue order): the per-row loss
+    // inputs first, then the 96 KiB of activation tiles, which stream in under the dY arithmetic.
+    const int prow = cbase + tid;
+    RowIn in;
+    row_issue(p, min(prow, B - 1), in);
+    float w2pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ec = min(tid + 256 * q, D * 32 - 1);      // clamped: unconditional load
+      w2pre[q] = w2[(ec >> 5) * HID + j0 + (ec & 31)];
+    }
+    // wave w reduces rows cbase + 64w + 16g + ks (ks = 0..15); rows >= B are clamped to a valid row:
+    // their dY is 0, so they contribute nothing.
+    f32x2 hh[16];
+    f32x4 bb[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int row = min(cbase + 64 * wave + 16 * g + ks, B - 1);
+      hh[ks] = *(const f32x2*)(H1g + row * HID + j0 + 2 * l15);
+      bb[ks] = *(const f32x4*)(H0g + row * HID + i0 + 4 * l15);
+    }
+    STAMP(p, 10);
+    // ---- dY for the 256 rows of the chunk (thread = row)
     {
-      const int row = cbase + tid;
+      const int row = prow;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        if (e < D * 32) W2s[e] = w2pre[q];
+      }
       float lossA = 0.f, lossB = 0.f;
       float* dyrow = dYs + tid * DYLD;
       for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
       float* dlsrow = (designated && net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) ? (dLs + tid * DYLD) : nullptr;
       if (dlsrow) for (int dd = 0; dd < Dp; ++dd) dlsrow[dd] = 0.f;
-      if (row < B) row_loss_grad(p, net, row, dyrow, dlsrow, lossA, lossB);
-      for (int e = tid; e < D * 32; e += 256) {
-        const int dd = e >> 5, jj = e & 31;
-        W2s[dd * 32 + jj] = w2[(long long)dd * HID + j0 + jj];
-      }
+      const PiConst pc = pi_consts(p, net);
+      if (row < B) row_finish(p, net, row, in, pc, dyrow, dlsrow, lossA, lossB);
+      STAMP(p, 11);
       if (designated) {
-        // loss partial sums of this chunk
         const float sA = block_sum_256(lossA, rsm);
         if (net == IQLHIP_NET_V && tid == 0) p.sc.loss_parts[0 * 64 + c] = sA;
         if (net == IQLHIP_NET_PI && tid == 0) p.sc.loss_parts[3 * 64 + c] = sA;
@@ -463,84 +637,91 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); sl += __shfl_xor(sl, o); }
         if (lane == 0) {
-          slab[nl.b2 + dd] = s;
+          slab[go.b2 + dd] = s;
           if (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) {
-            const float lsr = p.params[nl.log_std + dd];
+            const float lsr = p.log_std[dd];
             const bool inside = (lsr >= p.hy.log_std_min) && (lsr <= p.hy.log_std_max);
-            slab[nl.log_std + dd] = inside ? sl * p.inv_batch : 0.f;
+            slab[go.log_std + dd] = inside ? sl * p.inv_batch : 0.f;
           }
         }
       }
     }
-
     STAMP(p, 2);
-    // ---- main loop: this wave reduces rows [cbase + 64*wave, +64)
+
+    // ---- operand phase: A values av[ks][ta] = dH1[row][j0 + 2*l15 + ta] from registers + LDS
+    float av[16][2];
+    float db1a[2] = {0.f, 0.f};
+    float dw2a[2] = {0.f, 0.f};    // D == 1
+    const int rbase = 64 * wave + 16 * g;
+    if (D == 1) {
+      const float w2a = W2s[2 * l15], w2b = W2s[2 * l15 + 1];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const float dy = dYs[(rbase + ks) * DYLD];
+        av[ks][0] = (hh[ks][0] > 0.f) ? dy * w2a : 0.f;
+        av[ks][1] = (hh[ks][1] > 0.f) ? dy * w2b : 0.f;
+        if (extras) {
+          dw2a[0] = fmaf(dy, hh[ks][0], dw2a[0]);
+          dw2a[1] = fmaf(dy, hh[ks][1], dw2a[1]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) { av[ks][0] = 0.f; av[ks][1] = 0.f; }
+      for (int dd = 0; dd < D; ++dd) {
+        const float wa = W2s[dd * 32 + 2 * l15], wb = W2s[dd * 32 + 2 * l15 + 1];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const float dy = dYs[(rbase + ks) * DYLD + dd];
+          av[ks][0] = fmaf(dy, wa, av[ks][0]);
+          av[ks][1] = fmaf(dy, wb, av[ks][1]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        av[ks][0] = (hh[ks][0] > 0.f) ? av[ks][0] : 0.f;
+        av[ks][1] = (hh[ks][1] > 0.f) ? av[ks][1] : 0.f;
+      }
+    }
+    if (extras) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) { db1a[0] += av[ks][0]; db1a[1] += av[ks][1]; }
+    }
+
+    // ---- MFMA phase
     f32x4 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 acc2[2][2];   // dW2 tiles [dt][tb] (MFMA path, D > 1)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = MFMA16(av[ks][ta], bb[ks][tb], acc[ta][tb]);
+    }
+    f32x4 acc2[2][2];   // dW2 tiles [dt][tb] (MFMA path, D > 1, extras blocks only)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float db1a[2] = {0.f, 0.f};
-    float dw2a[2] = {0.f, 0.f};    // D == 1 VALU path
-    const bool extras = (it == 0);
     const int ndt = Dp >> 4;
-
-    f32x2 hh[16];
-    f32x4 bb[16];
+    if (extras && D > 1) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      // rows >= B are clamped to a valid row: their dY is 0, so they contribute nothing
-      // (no per-load branch: a select around each load would serialise the prefetch)
-      const int rl = 64 * wave + 4 * ks + g;
-      const int row = min(cbase + rl, B - 1);
-      hh[ks] = *(const f32x2*)(H1g + (long long)row * HID + j0 + 2 * l15);
-      bb[ks] = *(const f32x4*)(H0g + (long long)row * HID + i0 + 4 * l15);
-    }
+      for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int rl = 64 * wave + 4 * ks + g;
-      float av[2];
-      if (D == 1) {
-        const float dy = dYs[rl * DYLD];
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta) av[ta] = (hh[ks][ta] > 0.f) ? dy * W2s[2 * l15 + ta] : 0.f;
-        if (extras) {
-          dw2a[0] = fmaf(dy, hh[ks][0], dw2a[0]);
-          dw2a[1] = fmaf(dy, hh[ks][1], dw2a[1]);
-        }
-      } else {
-        float s0 = 0.f, s1 = 0.f;
-        for (int dd = 0; dd < D; ++dd) {
-          const float dy = dYs[rl * DYLD + dd];
-          s0 = fmaf(dy, W2s[dd * 32 + 2 * l15], s0);
-          s1 = fmaf(dy, W2s[dd * 32 + 2 * l15 + 1], s1);
-        }
-        av[0] = (hh[ks][0] > 0.f) ? s0 : 0.f;
-        av[1] = (hh[ks][1] > 0.f) ? s1 : 0.f;
-        if (extras) {
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            if (dt < ndt) {
-              const float ad = dYs[rl * DYLD + 16 * dt + l15];
-              acc2[dt][0] = MFMA16(ad, hh[ks][0], acc2[dt][0]);
-              acc2[dt][1] = MFMA16(ad, hh[ks][1], acc2[dt][1]);
-            }
+        for (int dt = 0; dt < 2; ++dt) {
+          if (dt < ndt) {
+            const float ad = dYs[(rbase + ks) * DYLD + 16 * dt + l15];
+            acc2[dt][0] = MFMA16(ad, hh[ks][0], acc2[dt][0]);
+            acc2[dt][1] = MFMA16(ad, hh[ks][1], acc2[dt][1]);
           }
         }
       }
-      if (extras) { db1a[0] += av[0]; db1a[1] += av[1]; }
-#pragma unroll
-      for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = MFMA16(av[ta], bb[ks][tb], acc[ta][tb]);
     }
-
     STAMP(p, 3);
+
     // ---- cross-wave reduction of the 32x64 tile through LDS, then coalesced store
     {
       float* myred = red + wave * 32 * T64_LD;
@@ -555,7 +736,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     }
     __syncthreads();
     {
-      float* gw1 = slab + nl.w1;
+      float* gw1 = slab + go.w1;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int f = tid + 256 * q;
@@ -563,7 +744,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         f32x4 s = *(const f32x4*)(red + jl * T64_LD + 4 * i4);
 #pragma unroll
         for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + w * 32 * T64_LD + jl * T64_LD + 4 * i4);
-        *(f32x4*)(gw1 + (long long)(j0 + jl) * HID + i0 + 4 * i4) = s;
+        *(f32x4*)(gw1 + (j0 + jl) * HID + i0 + 4 * i4) = s;
       }
     }
     if (extras) {
@@ -598,8 +779,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         const int rr = e >> 5, jj = e & 31;
         const float s = (ex[(0 * 33 + rr) * 32 + jj] + ex[(1 * 33 + rr) * 32 + jj]) +
                         (ex[(2 * 33 + rr) * 32 + jj] + ex[(3 * 33 + rr) * 32 + jj]);
-        if (rr == 0) slab[nl.b1 + j0 + jj] = s;
-        else slab[nl.w2 + (long long)(rr - 1) * HID + j0 + jj] = s;
+        if (rr == 0) slab[go.b1 + j0 + jj] = s;
+        else slab[go.w2 + (rr - 1) * HID + j0 + jj] = s;
       }
     }
     STAMP(p, 4);
@@ -613,31 +794,62 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     const int is = lb & 3;
     const int i0 = is * 64;
     const int row0 = rt * RT_ROWS;
-    const int k0 = nl.k_in;
-    const int k0p = (k0 + 3) & ~3;
-    const int xld = xld_for(k0p);
-    const float* w1 = p.params + nl.w1;
+    const int k0 = np.k0;
+    const int ld = p.ld;
+    const int xoff = 0;                   // trainable nets read s or [s|a]: both start at column 0
+    const float* w1 = np.w1;
 
     float* dH1s = smem;                              // [32][H0_LD]
     float* red = dH1s + RT_ROWS * H0_LD;             // [4][32][T64_LD]
     float* dH0s = red + 4 * 32 * T64_LD;             // [32][T64_LD]
     float* dYs = dH0s + RT_ROWS * T64_LD;            // [32][DYLD]
-    float* Xs = dYs + RT_ROWS * 33;                  // [32][xld]
+    float* Xr = dYs + RT_ROWS * 33;                  // [32][ld] packed rows (parked late); 1056 floats -> 16-B aligned
 
-    // prefetch this wave's W1 fragments: k = j in [64*wave, +64), n = i0 + 4*l15 + t
+    // ---- issue every global load of the block, first-needed first (vmcnt retires in issue order)
+    RowIn in;
+    const int prow = min(row0 + (tid & 31), B - 1);
+    row_issue(p, prow, in);
+    // W2 rows matching this thread's H1 columns (all threads use cols 4*(tid&63)); D == 1 fast path
+    const int j4 = tid & 63;
+    const f32x4 w2v = *(const f32x4*)(w2 + 4 * j4);
+    // H1 tile [32][256] as float4 f = tid + 256q: row f>>6, cols 4*(f&63)
+    f32x4 h1v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int f = tid + 256 * q;
+      const int row = min(row0 + (f >> 6), B - 1);   // rows >= B: dY = 0 -> dH1 = 0
+      h1v[q] = *(const f32x4*)(H1g + row * HID + 4 * (f & 63));
+    }
+    // W1 fragments: k = j in [64*wave, +64), n = i0 + 4*l15 + t
     f32x4 bw[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-      bw[ks] = *(const f32x4*)(w1 + (long long)(64 * wave + 4 * ks + g) * HID + i0 + 4 * l15);
+      bw[ks] = *(const f32x4*)(w1 + (64 * wave + 4 * ks + g) * HID + i0 + 4 * l15);
+    // H0 mask slice [32][64] as float4 f = tid + 256q: row f>>4, cols i0 + 4*(f&15)
+    f32x4 h0v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int f = tid + 256 * q;
+      const int row = min(row0 + (f >> 4), B - 1);
+      h0v[q] = *(const f32x4*)(H0g + row * HID + i0 + 4 * (f & 15));
+    }
+    // the 32 packed rows (needed last, for dW0)
+    const int n_x = RT_ROWS * ld / 4;
+    const int x_last = B * ld / 4 - 1;
+    f32x4 xr[XR_MAX_F4];
+#pragma unroll
+    for (int q = 0; q < XR_MAX_F4; ++q) {
+      const int f = min(row0 * ld / 4 + min(tid + 256 * q, n_x - 1), x_last);
+      xr[q] = *(const f32x4*)(p.xb + 4 * f);
+    }
 
-    const int kind = (net == IQLHIP_NET_Q1 || net == IQLHIP_NET_Q2) ? 2 : 0;
-    gather_rows(p, kind, row0, k0, xld, Xs);
+    const PiConst pc = pi_consts(p, net);
     if (tid < RT_ROWS) {
       const int row = row0 + tid;
       float la, lbv;
       float* dyrow = dYs + tid * DYLD;
       for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
-      if (row < B) row_loss_grad(p, net, row, dyrow, nullptr, la, lbv);
+      if (row < B) row_finish(p, net, row, in, pc, dyrow, nullptr, la, lbv);
     }
     __syncthreads();
     STAMP(p, 5);
@@ -645,19 +857,26 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // dH1s[r][j] = (sum_dd dY[r][dd] W2[dd][j]) * (H1[r][j] > 0)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int f = tid + 256 * q;      // float4 index in [32][64]
-      const int rl = f >> 6, j4 = f & 63;
-      const int row = min(row0 + rl, B - 1);   // rows >= B: dY = 0 -> dH1 = 0
-      f32x4 out;
-      const f32x4 h = *(const f32x4*)(H1g + (long long)row * HID + 4 * j4);
-      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int dd = 0; dd < D; ++dd) {
-        const float dy = dYs[rl * DYLD + dd];
-        const f32x4 wv = *(const f32x4*)(w2 + (long long)dd * HID + 4 * j4);
-        s += dy * wv;
-      }
+      const int rl = (tid + 256 * q) >> 6;
+      f32x4 s;
+      if (D == 1) {
+        s = dYs[rl * DYLD] * w2v;
+      } else {
+        s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int d0 = 0; d0 < D; d0 += 8) {
+          f32x4 wv[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[e] = (h[e] > 0.f) ? s[e] : 0.f;
+          for (int j = 0; j < 8; ++j) wv[j] = *(const f32x4*)(w2 + min(d0 + j, D - 1) * HID + 4 * j4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float dy = (d0 + j < D) ? dYs[rl * DYLD + min(d0 + j, D - 1)] : 0.f;
+            s += dy * wv[j];
+          }
+        }
+      }
+      f32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] : 0.f;
       *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
     }
     __syncthreads();
@@ -691,71 +910,87 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           *(f32x4*)(myred + rl * T64_LD + 4 * l15) = v;
         }
     }
+    // park the packed rows for the dW0 product
+#pragma unroll
+    for (int q = 0; q < XR_MAX_F4; ++q) {
+      const int f = tid + 256 * q;
+      if (f < n_x) *(f32x4*)(Xr + 4 * f) = xr[q];
+    }
     __syncthreads();
     STAMP(p, 7);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int f = tid + 256 * q;
       const int rl = f >> 4, i4 = f & 15;
-      const int row = min(row0 + rl, B - 1);   // rows >= B carry s = 0
       f32x4 s = *(const f32x4*)(red + rl * T64_LD + 4 * i4);
 #pragma unroll
       for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + w * 32 * T64_LD + rl * T64_LD + 4 * i4);
       f32x4 out;
-      const f32x4 h = *(const f32x4*)(H0g + (long long)row * HID + i0 + 4 * i4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[e] = (h[e] > 0.f) ? s[e] : 0.f;
+      for (int e = 0; e < 4; ++e) out[e] = (h0v[q][e] > 0.f) ? s[e] : 0.f;   // rows >= B carry s = 0
       *(f32x4*)(dH0s + rl * T64_LD + 4 * i4) = out;
     }
     __syncthreads();
 
     STAMP(p, 8);
-    float* slabB = p.sc.slab_b + p.sc.slab_b_off[net] + (long long)rt * (HID * k0 + HID);
-    // dW0[i][kc] partial = sum_r dH0[r][i] X[r][kc];  this wave: i in [i0 + 16*wave, +16)
+    float* slabB = p.sc.slab_b + p.sc.slab_b_off[net] + rt * (HID * k0 + HID);
+    // [dW0 | db0][i][kc] partial = sum_r dH0[r][i] * [X | 1][r][kc].  A = [X|1] (m = kc), B = dH0 (n = i):
+    // a lane's 4 accumulator registers are 4 consecutive kc of one i.  This wave: i in [i0 + 16*wave, +16).
     {
-      const int nct = (k0 + 15) >> 4;
-      f32x4 acc[8];
+      const int k1 = k0 + 1;
+      const int nct = (k1 + 15) >> 4;
+      f32x4 acc[9];
 #pragma unroll
-      for (int ct = 0; ct < 8; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < 9; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float bv[8];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int rl = 4 * ks + g;
-        const float a = dH0s[rl * T64_LD + 16 * wave + l15];
+      for (int ks = 0; ks < 8; ++ks) bv[ks] = dH0s[(4 * ks + g) * T64_LD + 16 * wave + l15];
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-          if (ct < nct) {
-            const int kc = 16 * ct + l15;
-            const float bv = (kc < xld) ? Xs[rl * xld + kc] : 0.f;
-            acc[ct] = MFMA16(a, bv, acc[ct]);
+      for (int ct = 0; ct < 9; ++ct) {
+        if (ct < nct) {
+          const int kc = 16 * ct + l15;
+          const int kcc = min(kc, k0 - 1);
+          float xa[8];
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) xa[ks] = Xr[(4 * ks + g) * ld + xoff + kcc];
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const float a = (kc < k0) ? xa[ks] : ((kc == k0) ? 1.f : 0.f);   // ones column -> db0
+            acc[ct] = MFMA16(a, bv[ks], acc[ct]);
           }
         }
       }
+      // stage the [64 i][k0] tile (and db0[64]) in LDS (the cross-wave buffer is free now), then flat float4 stores
+      float* T = red;                 // [64][k0]
+      float* Tb = red + 64 * IQLHIP_MAX_INPUT;   // [64]
 #pragma unroll
-      for (int ct = 0; ct < 8; ++ct) {
+      for (int ct = 0; ct < 9; ++ct) {
         if (ct < nct) {
-          const int kc = 16 * ct + l15;
-          if (kc < k0) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const int i = i0 + 16 * wave + 4 * g + reg;
-              slabB[(long long)i * k0 + kc] = acc[ct][reg];
-            }
+          for (int reg = 0; reg < 4; ++reg) {
+            const int kc = 16 * ct + 4 * g + reg;
+            const int il = 16 * wave + l15;
+            if (kc < k0) T[il * k0 + kc] = acc[ct][reg];
+            else if (kc == k0) Tb[il] = acc[ct][reg];
           }
         }
       }
     }
-    if (tid < 64) {
-      float s = 0.f;
-#pragma unroll
-      for (int rl = 0; rl < RT_ROWS; ++rl) s += dH0s[rl * T64_LD + tid];
-      slabB[(long long)HID * k0 + i0 + tid] = s;
+    __syncthreads();
+    {
+      const float* T = red;
+      const float* Tb = red + 64 * IQLHIP_MAX_INPUT;
+      float* dst = slabB + i0 * k0;      // 64*k0 contiguous floats, 16-B aligned (i0 % 16 == 0)
+      const int nf4 = 16 * k0;                       // = 64*k0/4
+      for (int f = tid; f < nf4; f += 256) *(f32x4*)(dst + 4 * f) = *(const f32x4*)(T + 4 * f);
+      if (tid < 16) *(f32x4*)(slabB + HID * k0 + i0 + 4 * tid) = *(const f32x4*)(Tb + 4 * tid);
     }
     STAMP(p, 9);
   }
 }
 
 // ---------------------------------------------------------------------------
-// Gradient assembly: element e (float4 granularity) of the flat arena.
+// Gradient assembly + Adam + Polyak.  Element e (float4 granularity) of the flat arena.
 struct UpdParams {
   iqlhip_layout L;
   iqlhip_step_scalars sc;
@@ -776,6 +1011,13 @@ struct UpdParams {
   int batch_rows;
   const iqlhip_step_scalars* sched;  // when non-null the scalars of this launch are sched[sched_idx]
   int sched_idx;                     // (hipGraph replay: kernel arguments are frozen, the table is not)
+  // next step's batch: extra blocks copy rows[idx[r]] -> xb[r] (whole padded rows, float4)
+  int n_upd_blocks;
+  const float* g_rows;
+  long long g_ld;
+  const long long* g_idx;   // nullable: no gather blocks
+  float* g_xb;
+  int g_n;
 };
 
 __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
@@ -788,12 +1030,27 @@ __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
 __device__ __forceinline__ f32x4 slab_grad(const UpdParams& u, long long e, int net) {
   const iqlhip_net_layout& nl = u.L.net[net];
   f32x4 gsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // slabs are read 8 at a time with unconditional (clamped) loads: a load inside a runtime-count loop
+  // would be waited for individually — one dependent round trip per slab.
+  const float* base;
+  long long stride;
+  int n;
   if (e >= nl.w0 && e < nl.b0 + HID) {
-    const long long len = (long long)HID * nl.k_in + HID;
-    const float* base = u.slab_b + u.slab_b_off[net] + (e - nl.w0);
-    for (int rt = 0; rt < u.n_rt; ++rt) gsum += *(const f32x4*)(base + rt * len);
+    stride = (long long)HID * nl.k_in + HID;
+    base = u.slab_b + u.slab_b_off[net] + (e - nl.w0);
+    n = u.n_rt;
   } else {
-    for (int c = 0; c < u.n_chunk; ++c) gsum += *(const f32x4*)(u.slab_a + (long long)c * u.L.n_params + e);
+    stride = u.L.n_params;
+    base = u.slab_a + e;
+    n = u.n_chunk;
+  }
+  if (n == 1) return *(const f32x4*)base;
+  for (int r0 = 0; r0 < n; r0 += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(base + (long long)min(r0 + j, n - 1) * stride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (r0 + j < n) gsum += v[j];
   }
   return gsum;
 }
@@ -807,6 +1064,22 @@ __device__ __forceinline__ void loss_words(const UpdParams& u, float out[4]) {
   out[1] = s[1];   // sum_r e1^2
   out[2] = s[2];   // sum_r e2^2
   out[3] = s[3];   // sum_r w bc
+}
+
+// rows[idx[r]] -> xb[r], r < n: one float4 per thread-iteration (rows are 16-B aligned, ld % 4 == 0)
+__device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld, const long long* idx, float* xb,
+                                                 int n, int first, int stride) {
+  const int q = (int)(ld >> 2);
+  const int total = n * q;
+  for (int e = first; e < total; e += stride) {
+    const int r = e / q, c4 = e - r * q;
+    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = *(const f32x4*)(rows + idx[r] * ld + 4 * c4);
+  }
+}
+
+__global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long long ld, const long long* idx,
+                                                         float* xb, int n) {
+  gather_rows_flat(rows, ld, idx, xb, n, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // Writes the summed flat gradient (+ tail: value, q, actor loss contributions, spare) for the DP all-reduce.
@@ -827,22 +1100,42 @@ __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, floa
   }
 }
 
+// FROM_TABLE: the per-step scalars come from the device table u.sched[u.sched_idx] (hipGraph replay: kernel
+// arguments are frozen, the table is not); otherwise from the kernel argument u.sc.  Two instantiations
+// rather than a run-time pointer select, which would turn every access into a flat load.
+template <bool FROM_TABLE>
 __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
+  if ((int)blockIdx.x >= u.n_upd_blocks) {
+    // gather blocks: stage the next step's rows while the optimizer blocks run
+    const int gb = (int)blockIdx.x - u.n_upd_blocks;
+    const int ngb = (int)gridDim.x - u.n_upd_blocks;
+    gather_rows_flat(u.g_rows, u.g_ld, u.g_idx, u.g_xb, u.g_n, gb * 256 + threadIdx.x, ngb * 256);
+    return;
+  }
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (e < u.L.n_params) {
     const int net = net_of(u.L, e);
+    // issue the state loads before the gradient sum so that all of them are in flight together
+    f32x4 m = *(f32x4*)(u.m + e);
+    f32x4 v = *(f32x4*)(u.v + e);
+    f32x4 pw = *(f32x4*)(u.params + e);
+    const bool is_q = (net == IQLHIP_NET_Q1 || net == IQLHIP_NET_Q2);
+    float* tp = u.target + (is_q ? (e - u.L.target_src) : 0);
+    f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (is_q) t = *(f32x4*)tp;
     f32x4 gr;
     if (u.flat_grads) gr = *(const f32x4*)(u.flat_grads + e);
     else gr = slab_grad(u, e, net);
     const int grp = (net == IQLHIP_NET_V) ? 0 : ((net == IQLHIP_NET_PI) ? 2 : 1);
-    const iqlhip_step_scalars* scp = u.sched ? (u.sched + u.sched_idx) : &u.sc;
-    const float gs = scp->grad_scale;
-    const float step = -scp->step_size[grp];
-    const float bc2 = scp->bc2_sqrt[grp];
-    const float omb1 = scp->one_minus_beta1, b2 = scp->beta2, omb2 = scp->one_minus_beta2, eps = scp->eps;
-    f32x4 m = *(f32x4*)(u.m + e);
-    f32x4 v = *(f32x4*)(u.v + e);
-    f32x4 pw = *(f32x4*)(u.params + e);
+    // (copy by value: a pointer that may address either the kernarg segment or global memory would make
+    //  every access a flat load)
+    iqlhip_step_scalars sc;
+    if (FROM_TABLE) sc = u.sched[u.sched_idx];
+    else sc = u.sc;
+    const float gs = sc.grad_scale;
+    const float step = -((grp == 0) ? sc.step_size[0] : ((grp == 1) ? sc.step_size[1] : sc.step_size[2]));
+    const float bc2 = (grp == 0) ? sc.bc2_sqrt[0] : ((grp == 1) ? sc.bc2_sqrt[1] : sc.bc2_sqrt[2]);
+    const float omb1 = sc.one_minus_beta1, b2 = sc.beta2, omb2 = sc.one_minus_beta2, eps = sc.eps;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gk = (gs == 1.f) ? gr[k] : gr[k] * gs;
@@ -854,9 +1147,7 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     *(f32x4*)(u.m + e) = m;
     *(f32x4*)(u.v + e) = v;
     *(f32x4*)(u.params + e) = pw;
-    if (net == IQLHIP_NET_Q1 || net == IQLHIP_NET_Q2) {
-      float* tp = u.target + (e - u.L.target_src);
-      f32x4 t = *(f32x4*)tp;
+    if (is_q) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] = u.one_minus_tau * t[k] + u.tau * pw[k];
       *(f32x4*)tp = t;
@@ -881,6 +1172,24 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
       float* rr = u.loss_ring + 4 * (long long)u.ring_slot;
       rr[0] = l[0]; rr[1] = l[1]; rr[2] = l[2]; rr[3] = 0.f;
     }
+  }
+}
+
+// Five row-major arrays (any strides) -> packed rows [s | a | s' | r | d | pad] of the staging batch.
+__global__ void iql_pack_kernel(float* xb, int ld, int S, int A, int n, const float* s, long long ld_s, const float* a,
+                                long long ld_a, const float* r, long long ld_r, const float* ns, long long ld_ns,
+                                const float* d, long long ld_d) {
+  const int total = n * ld;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int i = e / ld;
+    const int c = e - i * ld;
+    float v = 0.f;
+    if (c < S) v = s[i * ld_s + c];
+    else if (c < S + A) v = a[i * ld_a + (c - S)];
+    else if (c < 2 * S + A) v = ns[i * ld_ns + (c - S - A)];
+    else if (c == 2 * S + A) v = r[i * ld_r];
+    else if (c == 2 * S + A + 1) v = d[i * ld_d];
+    xb[e] = v;
   }
 }
 

@@ -82,6 +82,8 @@ SYMBOLS = [
     ("iqlhip_draw_indices", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
     ("iqlhip_debug_read", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),
+    ("iqlhip_debug_time_kernel", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.POINTER(C.c_float),
+                                           C.c_void_p]),
     ("iqlhip_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("iqlhip_get_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 ]

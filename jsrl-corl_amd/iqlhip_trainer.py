@@ -547,6 +547,14 @@ class ImplicitQLearning:
         hb.check(hb.lib().iqlhip_get_timing(self._ctx, out))
         return [float(x) for x in out]
 
+    def time_kernel(self, batch: TensorBatch, which: int, repeat: int = 200) -> float:
+        """Average microseconds per launch of one kernel of the step, launched back to back."""
+        b, keep, B = self._batch_struct(batch)
+        self._prepare(B)
+        out = C.c_float(0)
+        hb.check(hb.lib().iqlhip_debug_time_kernel(self._ctx, C.byref(b), which, repeat, C.byref(out), self._stream()))
+        return float(out.value)
+
     def debug_read(self, name: str) -> np.ndarray:
         self._require_gpu()
         cap = 4 * self._max_batch * 256 + 64

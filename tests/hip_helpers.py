@@ -111,11 +111,9 @@ def head_values(tr, params, B):
     """Reconstruct next_v, v, qt1, qt2, q1, q2, pre-tanh pi from the library's head partials."""
     h = tr.debug_read("heads")
     MB, A = tr._max_batch, tr._A
-    sc = h[: 6 * 4 * MB].reshape(6, 4, MB)[:, :, :B]
-    pi = h[6 * 4 * MB: 6 * 4 * MB + 4 * MB * A].reshape(4, MB, A)[:, :B]
-    s = ((sc[:, 0] + sc[:, 1]) + sc[:, 2]) + sc[:, 3]
-    out = {"next_v": s[0] + params["vf"]["b2"][0], "v": s[1] + params["vf"]["b2"][0],
-           "qt1": s[2] + params["qt1"]["b2"][0], "qt2": s[3] + params["qt2"]["b2"][0],
-           "q1": s[4] + params["q1"]["b2"][0], "q2": s[5] + params["q2"]["b2"][0],
-           "pre": ((pi[0] + pi[1]) + pi[2]) + pi[3] + params["pi"]["b2"][None, :]}
+    sc = h[: MB * 24].reshape(MB, 6, 4)[:B].transpose(1, 2, 0)          # [inst][ns][row]
+    pi = h[MB * 24: MB * 24 + MB * A * 4].reshape(MB, A, 4)[:B].transpose(2, 0, 1)   # [ns][row][A]
+    s = ((sc[:, 0] + sc[:, 1]) + sc[:, 2]) + sc[:, 3]      # the bias is folded into slice 0 by the forward kernel
+    out = {"next_v": s[0], "v": s[1], "qt1": s[2], "qt2": s[3], "q1": s[4], "q2": s[5],
+           "pre": ((pi[0] + pi[1]) + pi[2]) + pi[3]}
     return out

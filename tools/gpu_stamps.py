@@ -67,7 +67,7 @@ ids = np.arange(nb)
 local = (ids >> 3) * 2 + ((ids & 7) >> 2)
 a_blocks = bw[local < 32 * n_chunk]
 b_blocks = bw[(local >= 32 * n_chunk) & (local < per_net)]
-report("bwd (a) dW1 tiles", a_blocks, [(1, "dY prologue (256 rows)"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
+report("bwd (a) dW1 tiles", a_blocks, [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
                                         (4, "reduce + store (+extras)")])
 report("bwd (b) dH0/dW0", b_blocks, [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"),
                                       (8, "reduce+mask"), (9, "dW0 MFMA + stores")])
