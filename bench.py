@@ -130,20 +130,22 @@ def main():
     log = tr.train(buf.sample(B)) if world == 1 else tr.train_on_buffer(buf, B, seed=1, sync=True)
     assert all(np.isfinite(v) for v in log.values()), log
 
-    # ---- roofline of the dominant kernel (backward), HIP events around each launch on the stream
+    # ---- roofline of the dominant kernel (backward): its average launch duration is measured live with
+    # HIP events on the launch stream around back-to-back launches of that kernel on the bench batch
+    # (iqlhip_debug_time_kernel; events around single ~10 us launches would add their own ~3 us).
     f_fwd, f_bwd = flops(S, A, B)
     roof = None
     if world == 1:
-        tr.set_timing(True)
-        for _ in range(300):
-            tr.train_on_buffer(buf, B, seed=99, sync=False)
-        t_fwd, t_bwd, t_upd, t_tot = tr.get_timing_us()
-        tr.set_timing(False)
+        batch = buf.sample(B)
+        t_fwd = tr.time_kernel(batch, 0, 500)
+        t_bwd = tr.time_kernel(batch, 1, 500)
+        t_upd = tr.time_kernel(batch, 2, 500)
         ach = f_bwd / (t_bwd * 1e-6) / 1e12
         roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                 "flops_per_launch": f_bwd, "avg_launch_us": round(t_bwd, 3),
-                "event_us": {"fwd": round(t_fwd, 3), "bwd": round(t_bwd, 3), "update": round(t_upd, 3)},
+                "kernel_us": {"iql_fwd_kernel": round(t_fwd, 3), "iql_bwd_kernel": round(t_bwd, 3),
+                              "iql_update_kernel": round(t_upd, 3)},
                 "step_flops": f_fwd + f_bwd,
                 "step_frac_of_peak": round((f_fwd + f_bwd) * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
 

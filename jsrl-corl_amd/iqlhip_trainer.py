@@ -26,6 +26,7 @@ import torch.nn as nn
 from torch.optim.lr_scheduler import CosineAnnealingLR
 
 import iqlhip_binding as hb
+import iqlhip_dp as dp
 from iqlhip_networks import (DeterministicPolicy, GaussianPolicy, LOG_STD_MAX, LOG_STD_MIN, dropout_p,
                              linear_layers)
 
@@ -319,11 +320,12 @@ class ImplicitQLearning:
         sc = hb.StepScalars()
         lib = hb.lib()
         if self._dp_world > 1:
-            self._fill_scalars(sc, self._adam_t, self._current_lrs(), 1.0 / (B * self._dp_world))
+            self._fill_scalars(sc, self._adam_t, self._current_lrs(), dp.inv_batch(B, self._dp_world))
             flat = self._dp_flat()
             hb.check(lib.iqlhip_forward_backward(self._ctx, C.byref(b), C.byref(sc), flat.data_ptr(), self._stream()))
-            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self._dp_group)
-            hb.check(lib.iqlhip_apply_update(self._ctx, flat.data_ptr(), C.byref(sc), self._stream()))
+            dp.reduce_and_update(
+                flat, lambda f: hb.check(lib.iqlhip_apply_update(self._ctx, f.data_ptr(), C.byref(sc), self._stream())),
+                self._dp_group)
         else:
             self._fill_scalars(sc, self._adam_t, self._current_lrs(), 1.0 / B)
             hb.check(lib.iqlhip_step(self._ctx, C.byref(b), C.byref(sc), self._stream()))
@@ -447,7 +449,7 @@ class ImplicitQLearning:
             idx = torch.empty(batch_size, dtype=torch.int64, device=self._dev)
             self._idx_buf = idx
         rank = torch.distributed.get_rank(self._dp_group) if self._dp_world > 1 else 0
-        hb.check(lib.iqlhip_draw_indices(idx.data_ptr(), batch_size, size, (int(seed) + 0x9E3779B97F4A7C15 * rank) & 0xFFFFFFFFFFFFFFFF,
+        hb.check(lib.iqlhip_draw_indices(idx.data_ptr(), batch_size, size, dp.rank_seed(seed, rank),
                                          int(self.total_it) * ((batch_size + 1) // 2), self._stream()))
         S, A = self._S, self._A
         base = replay_buffer._rows.data_ptr()
@@ -466,9 +468,8 @@ class ImplicitQLearning:
         self._dp_group = process_group
         self._dp_world = dist.get_world_size(process_group)
         if self._dp_world > 1:
-            for arena in (self._params_arena, self._target_arena, self._m_arena, self._v_arena):
-                dist.broadcast(arena, src=dist.get_global_rank(process_group, 0) if process_group else 0,
-                               group=process_group)
+            dp.broadcast_state((self._params_arena, self._target_arena, self._m_arena, self._v_arena), process_group,
+                               src=dist.get_global_rank(process_group, 0) if process_group else 0)
 
     def _dp_flat(self) -> torch.Tensor:
         n = int(hb.lib().iqlhip_grad_words(self._ctx))
@@ -569,7 +570,7 @@ class ImplicitQLearning:
         self._prepare(B)
         sc = hb.StepScalars()
         t1 = {g: max(1, v) for g, v in self._adam_t.items()}
-        self._fill_scalars(sc, t1, self._current_lrs(), 1.0 / (B * self._dp_world))
+        self._fill_scalars(sc, t1, self._current_lrs(), dp.inv_batch(B, self._dp_world))
         flat = self._dp_flat()
         hb.check(hb.lib().iqlhip_forward_backward(self._ctx, C.byref(b), C.byref(sc), flat.data_ptr(), self._stream()))
         torch.cuda.synchronize(self._dev)

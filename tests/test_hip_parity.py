@@ -156,3 +156,83 @@ def test_error_behaviour_matches_reference():
     buf = iql.ReplayBuffer(S, A, 16, "cuda")
     with pytest.raises(ValueError, match="smaller than the dataset"):
         buf.load_d4rl_dataset(d)
+
+
+def test_split_step_equals_fused_step():
+    """forward_backward -> flat gradient -> apply_update (the data-parallel path, world = 1, no
+    collective) lands bitwise on the same parameters as the fused single-GPU step."""
+    build, _, _, read_params, to_tb, _ = _hip()
+    import ctypes as C
+    import iqlhip_binding as hb
+    S, A = 17, 6
+    params = synth.synth_params(S, A, seed=9)
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    d = synth.synth_transitions(256, S, A, seed=10)
+    batch = {"s": d["observations"], "a": d["actions"], "r": d["rewards"], "ns": d["next_observations"],
+             "d": d["terminals"]}
+    fused = build(params, S, A, True, hyper, lrs, 1000)
+    log = fused.train(to_tb(batch))
+    split = build(params, S, A, True, hyper, lrs, 1000)
+    b, keep, B = split._batch_struct(to_tb(batch))
+    split.total_it += 1
+    for g in split._adam_t:
+        split._adam_t[g] += 1
+    sc = hb.StepScalars()
+    split._fill_scalars(sc, split._adam_t, split._current_lrs(), 1.0 / B)
+    flat = split._dp_flat()
+    lib = hb.lib()
+    hb.check(lib.iqlhip_forward_backward(split._ctx, C.byref(b), C.byref(sc), flat.data_ptr(), split._stream()))
+    hb.check(lib.iqlhip_apply_update(split._ctx, flat.data_ptr(), C.byref(sc), split._stream()))
+    out = (C.c_float * 3)()
+    hb.check(lib.iqlhip_read_losses(split._ctx, out, split._stream()))
+    assert [float(x) for x in out] == [log["value_loss"], log["q_loss"], log["actor_loss"]]
+    pa, pb = read_params(fused), read_params(split)
+    for n in pa:
+        for k in pa[n]:
+            assert np.array_equal(pa[n][k], pb[n][k]), (n, k)
+
+
+def test_train_steps_graph_matches_eager_steps_on_same_indices():
+    """K steps replayed as one hipGraph (device index draw, gather fused into the update kernel) equal
+    K eager steps fed with the same indices — bitwise."""
+    import ctypes as C
+    import iql
+    import iqlhip_binding as hb
+    build, _, _, read_params, _, _ = _hip()
+    S, A, N, B, K = 17, 6, 5000, 256, 7
+    params = synth.synth_params(S, A, seed=21)
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    data = synth.synth_transitions(N, S, A, seed=22)
+    buf = iql.ReplayBuffer(S, A, N, "cuda")
+    buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    g = build(params, S, A, True, hyper, lrs, 1000)
+    losses = g.train_steps(buf, K, B, seed=77)
+    assert losses.shape == (K, 3) and np.all(np.isfinite(losses)) and g.total_it == K
+    # replay the same index stream eagerly
+    e = build(params, S, A, True, hyper, lrs, 1000)
+    idx = torch.empty(K * B, dtype=torch.int64, device="cuda")
+    hb.check(hb.lib().iqlhip_draw_indices(idx.data_ptr(), K * B, N, 77, 0, torch.cuda.current_stream().cuda_stream))
+    assert int(idx.min()) >= 0 and int(idx.max()) < N
+    for k in range(K):
+        log = e.train(buf.gather(idx[k * B:(k + 1) * B]))
+        assert [log["value_loss"], log["q_loss"], log["actor_loss"]] == [float(x) for x in losses[k]]
+    pa, pb = read_params(g), read_params(e)
+    for n in pa:
+        for kk in pa[n]:
+            assert np.array_equal(pa[n][kk], pb[n][kk]), (n, kk)
+    assert g.actor_optimizer.param_groups[0]["lr"] == e.actor_optimizer.param_groups[0]["lr"]
+    sd = g.state_dict()
+    assert float(sd["q_optimizer"]["state"][0]["step"]) == K
+
+
+def test_device_index_draw_is_uniform():
+    import iqlhip_binding as hb
+    n, size = 1 << 20, 1000
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    hb.check(hb.lib().iqlhip_draw_indices(idx.data_ptr(), n, size, 123, 0, torch.cuda.current_stream().cuda_stream))
+    c = torch.bincount(idx, minlength=size).double().cpu().numpy()
+    assert c.sum() == n and c.min() > 0
+    chi2 = float(((c - n / size) ** 2 / (n / size)).sum())
+    assert 800 < chi2 < 1250, chi2      # 999 dof: mean 999, sd ~45

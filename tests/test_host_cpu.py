@@ -1,0 +1,233 @@
+"""CPU-only tests (no GPU in the process): the C-ABI library loads and exports every
+symbol include/iqlhip.h declares, the arena layout is what the shim relies on, and the
+host logic of the drop-in classes (ReplayBuffer bookkeeping, checkpoint format, LR
+schedule fast path, config dataclasses, error behaviour) matches the reference's,
+pinned by the reference-generated fixtures g3..g6."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import iql
+import iqlhip_binding as hb
+import synth
+from helpers import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "iqlhip.h")).read()
+    declared = set(re.findall(r"\b(iqlhip_[a-z_0-9]+)\s*\(", header))
+    declared -= {"iqlhip_ctx"}
+    bound = {name for name, _, _ in hb.SYMBOLS}
+    assert declared == bound, f"header vs binding mismatch: {declared ^ bound}"
+    lib = hb.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.iqlhip_version() >= 100
+
+
+def test_arena_layout_is_consistent():
+    for (S, A, gauss) in ((17, 6, True), (29, 8, False), (39, 28, True), (3, 2, True)):
+        L = hb.arena_layout(S, A, gauss)
+        prev_end = 0
+        for i, nl in enumerate(L.net):
+            k = S + A if i in (hb.NET_Q1, hb.NET_Q2) else S
+            d = A if i == hb.NET_PI else 1
+            assert (nl.k_in, nl.d_out) == (k, d)
+            assert nl.seg_begin == prev_end and nl.seg_begin % 64 == 0 and nl.seg_end % 64 == 0
+            assert nl.w1 == nl.seg_begin and nl.w0 == nl.w1 + 256 * 256 and nl.b0 == nl.w0 + 256 * k
+            assert nl.b1 == nl.b0 + 256 and nl.w2 == nl.b1 + 256 and nl.b2 == nl.w2 + d * 256
+            for off in (nl.w0, nl.b0, nl.w1, nl.b1, nl.w2, nl.b2):
+                assert off % 4 == 0
+            if i == hb.NET_PI and gauss:
+                assert nl.log_std == nl.b2 + (d + 3) // 4 * 4
+            else:
+                assert nl.log_std == -1
+            prev_end = nl.seg_end
+        assert L.n_params == prev_end
+        assert L.target_src == L.net[hb.NET_Q1].seg_begin
+        assert L.n_target == L.net[hb.NET_Q2].seg_end - L.net[hb.NET_Q1].seg_begin
+    assert hb.row_stride(17, 6) == 44 and hb.row_stride(29, 8) == 68 and hb.row_stride(39, 28) == 108
+
+
+def test_error_codes_map_to_reference_exception_types():
+    with pytest.raises(NotImplementedError):
+        hb.arena_layout(17, 6, True, hidden_dim=128)
+    with pytest.raises(NotImplementedError):
+        hb.arena_layout(100, 40, True)
+    with pytest.raises(ValueError):
+        hb.arena_layout(0, 6, True)
+
+
+# ---------------------------------------------------------------- replay buffer host logic
+def test_replay_buffer_sample_matches_reference_fixture():
+    z, meta = load_golden("g3_gather")
+    data = synth.synth_transitions(meta["N"], meta["S"], meta["A"], seed=meta["data_seed"])
+    buf = iql.ReplayBuffer(meta["S"], meta["A"], meta["capacity"], "cpu")
+    buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    assert (buf._size, buf._pointer) == (meta["size"], meta["pointer"])
+    np.random.seed(meta["np_seed"])
+    s, a, r, ns, d = buf.sample(meta["B"])
+    for got, key in ((s, "s"), (a, "a"), (r, "r"), (ns, "ns"), (d, "d")):
+        assert tuple(got.shape) == z[key].shape
+        assert np.array_equal(got.numpy(), z[key]), key
+    # the reference's attribute views
+    assert buf._states.shape == (meta["capacity"], meta["S"]) and buf._rewards.shape == (meta["capacity"], 1)
+    assert np.array_equal(buf._states[: meta["N"]].numpy(), data["observations"])
+    assert np.array_equal(buf._dones[: meta["N"], 0].numpy(), data["terminals"])
+
+
+def test_replay_buffer_ring_insert_matches_reference_fixture():
+    z, meta = load_golden("g4_ring")
+    S, A, cap = meta["S"], meta["A"], meta["capacity"]
+    data = synth.synth_transitions(5, S, A, seed=meta["load_seed"])
+    extra = synth.synth_transitions(7, S, A, seed=meta["extra_seed"])
+    buf = iql.ReplayBuffer(S, A, cap, "cpu")
+    buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    trace = [(buf._pointer, buf._size)]
+    for i in range(7):
+        buf.add_transition(extra["observations"][i], extra["actions"][i], float(extra["rewards"][i]),
+                           extra["next_observations"][i], bool(extra["terminals"][i] > 0.5 or i == 2))
+        trace.append((buf._pointer, buf._size))
+    assert np.array_equal(np.array(trace), z["trace"])
+    for attr, key in (("_states", "states"), ("_actions", "actions"), ("_rewards", "rewards"),
+                      ("_next_states", "next_states"), ("_dones", "dones")):
+        assert np.array_equal(getattr(buf, attr).numpy(), z[key]), key
+    with pytest.raises(ValueError) as e1:
+        buf.load_d4rl_dataset(data)
+    assert str(e1.value) == meta["errors"]["nonempty"]
+    with pytest.raises(ValueError) as e2:
+        iql.ReplayBuffer(S, A, 3, "cpu").load_d4rl_dataset(data)
+    assert str(e2.value) == meta["errors"]["too_small"]
+
+
+def test_offline_buffer_flavour():
+    buf = iql.OfflineReplayBuffer(3, 2, 16, "cpu")
+    buf.load_d4rl_dataset(synth.synth_transitions(10, 3, 2, seed=1))
+    assert buf._index_bound() == 10
+    with pytest.raises(NotImplementedError):
+        buf.add_transition()
+
+
+# ---------------------------------------------------------------- trainer host logic
+def _cpu_trainer(S=17, A=6, gaussian=True, max_steps=1000):
+    qf, vf = iql.TwinQ(S, A), iql.ValueFunction(S)
+    actor = (iql.GaussianPolicy if gaussian else iql.DeterministicPolicy)(S, A, 1.0)
+    return iql.ImplicitQLearning(
+        1.0, actor, torch.optim.Adam(actor.parameters(), lr=3e-4), qf, torch.optim.Adam(qf.parameters(), lr=3e-4),
+        vf, torch.optim.Adam(vf.parameters(), lr=3e-4), max_steps=max_steps, device="cpu")
+
+
+def test_state_dict_format_matches_reference_fixture():
+    z, meta = load_golden("g6_statedict")
+    tr = _cpu_trainer()
+    sd = tr.state_dict()
+    assert list(sd.keys()) == meta["top_keys"]
+    for k in ("qf", "vf", "actor"):
+        assert {kk: list(vv.shape) for kk, vv in sd[k].items()} == meta[k]
+    assert sorted(sd["actor_lr_schedule"].keys()) == sorted(meta["actor_lr_schedule"].keys())
+    for k in ("q_optimizer", "v_optimizer", "actor_optimizer"):
+        assert sorted(sd[k]["param_groups"][0].keys()) == meta[k]["param_group_keys"]
+        assert sd[k]["param_groups"][0]["params"] == meta[k]["params"]
+    # round trip + the reference's quirk: after load the target equals qf and is trainable-flagged
+    tr2 = _cpu_trainer()
+    tr2.load_state_dict(sd)
+    assert all(torch.equal(a, b) for a, b in zip(tr2.q_target.parameters(), tr2.qf.parameters()))
+    assert next(tr2.q_target.parameters()).requires_grad == meta["target_requires_grad_after_load"]
+    tr3 = _cpu_trainer()
+    before = [p.clone() for p in tr3.q_optimizer.param_groups[0]["params"]]
+    tr3.partial_load_state_dict(sd)
+    assert tr3.total_it == sd["total_it"]
+    assert all(torch.equal(a, b) for a, b in zip(tr3.qf.parameters(), tr.qf.parameters()))
+    assert len(tr3.q_optimizer.state) == 0 and len(before) == 12
+
+
+def test_cpu_device_has_no_step():
+    tr = _cpu_trainer()
+    with pytest.raises(RuntimeError, match="GPU"):
+        tr.train([torch.zeros(4, 17), torch.zeros(4, 6), torch.zeros(4, 1), torch.zeros(4, 17), torch.zeros(4, 1)])
+
+
+def test_fast_lr_schedule_equals_torch_scheduler():
+    z, meta = load_golden("g5_lr")
+    tr = _cpu_trainer(3, 2, True, max_steps=meta["T"])
+    got = np.concatenate([tr._advance_schedule(700), tr._advance_schedule(801)])
+    assert np.array_equal(got, z["lrs"])          # bit-equal to the reference's recursion, incl. the restart branch
+    assert tr.actor_lr_schedule.last_epoch == 1501
+    ref = _cpu_trainer(3, 2, True, max_steps=meta["T"])
+    for _ in range(1501):
+        ref._step_schedule()
+    assert ref.actor_lr_schedule.state_dict() == tr.actor_lr_schedule.state_dict()
+    none = _cpu_trainer(3, 2, True, max_steps=None)
+    assert none.actor_lr_schedule is None and np.all(none._advance_schedule(5) == 3e-4)
+
+
+def test_scalar_table_matches_torch_adam_scalars():
+    from oracle import iql_oracle as O
+    tr = _cpu_trainer(3, 2, True, max_steps=None)
+    tab = tr._scalar_table(10, 1.0 / 256)
+    for t in range(1, 11):
+        step_size, bc2 = O.adam_scalars(3e-4, t)
+        assert tab[t - 1, 0] == np.float32(step_size) and tab[t - 1, 3] == np.float32(bc2)
+    assert tab[0, 6] == np.float32(0.999) and tab[0, 7] == np.float32(1 - 0.9) and tab[0, 11] == np.float32(1 / 256)
+    assert tr._adam_t == {"v": 10, "q": 10, "pi": 10}
+
+
+def test_unsupported_configurations_fail_loudly():
+    tr = _cpu_trainer()
+    tr.v_optimizer.param_groups[0]["weight_decay"] = 0.1
+    with pytest.raises(NotImplementedError):
+        tr._adam_hyper()
+    with pytest.raises(ValueError):
+        iql.MLP([4])
+    with pytest.raises(ValueError):
+        iql.MLP([4, 8, 2], squeeze_output=True)
+    # dropout layers appear exactly when the reference creates them (finetune flavour: > 0)
+    assert not any(isinstance(m, torch.nn.Dropout) for m in iql.MLP([4, 8, 8, 2], dropout=0.0).modules())
+    assert sum(isinstance(m, torch.nn.Dropout) for m in iql.MLP([4, 8, 8, 2], dropout=0.1).modules()) == 2
+
+
+def test_train_config_fields_match_reference():
+    cfg = iql.TrainConfig()
+    want = ["device", "env", "seed", "eval_seed", "eval_freq", "n_episodes", "offline_iterations", "online_iterations",
+            "checkpoints_path", "load_model", "actor_dropout", "buffer_size", "batch_size", "discount", "tau", "beta",
+            "iql_tau", "expl_noise", "noise_clip", "iql_deterministic", "normalize", "normalize_reward", "vf_lr",
+            "qf_lr", "actor_lr", "project", "group", "name"]
+    assert list(cfg.__dataclass_fields__.keys()) == want
+    assert cfg.name.startswith("IQL-antmaze-umaze-v2-") and len(cfg.name.split("-")[-1]) == 8
+    assert (cfg.batch_size, cfg.tau, cfg.beta, cfg.iql_tau, cfg.buffer_size) == (256, 0.005, 3.0, 0.7, 2_000_000)
+    off = iql.OfflineTrainConfig(checkpoints_path="/tmp/x")
+    assert off.actor_dropout is None and off.max_timesteps == 1_000_000 and off.checkpoints_path.startswith("/tmp/x/IQL-")
+    # kw_only subclassing as in jsrl_w_iql.py:46 keeps working
+    from dataclasses import dataclass
+
+    @dataclass(kw_only=True)
+    class J(iql.TrainConfig):
+        n_curriculum_stages: int = 10
+    assert J(n_curriculum_stages=3).n_curriculum_stages == 3
+
+
+def test_module_surface_has_every_name_the_jsrl_files_import():
+    names = ["ENVS_WITH_GOAL", "DeterministicPolicy", "GaussianPolicy", "ImplicitQLearning", "ReplayBuffer",
+             "TrainConfig", "TwinQ", "ValueFunction", "compute_mean_std", "is_goal_reached", "modify_reward",
+             "modify_reward_online", "normalize_states", "set_env_seed", "set_seed", "wandb_init", "wrap_env", "Tuple",
+             "nn", "MLP", "soft_update", "asymmetric_l2_loss", "eval_actor", "return_reward_range"]
+    for n in names:
+        assert hasattr(iql, n), n
+
+
+def test_host_helpers():
+    d = {"rewards": np.array([1.0, 2.0, 3.0, 4.0], dtype=np.float32), "terminals": np.array([0, 1, 0, 0])}
+    assert iql.return_reward_range(d, 2) == (3.0, 7.0)
+    ds = {"rewards": np.ones(4, dtype=np.float32), "terminals": np.zeros(4)}
+    assert iql.modify_reward(ds, "antmaze-large-diverse-v2") == {} and np.all(ds["rewards"] == 0.0)
+    assert iql.modify_reward_online(1.0, "antmaze-x") == 0.0
+    m, s = iql.compute_mean_std(np.array([[0.0, 2.0], [2.0, 2.0]]), 1e-3)
+    assert np.allclose(m, [1.0, 2.0]) and np.allclose(s, [1.001, 0.001])
+    assert iql.is_goal_reached(0.0, {"success": True}) and not iql.is_goal_reached(0.0, {})
