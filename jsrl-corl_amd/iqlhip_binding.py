@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the IQL step.")
+        # torch first: libiqlhip.so needs libamdhip64; loading it before torch would bind the system ROCm
+        # runtime while torch brings its own copy — two HIP runtimes in one process, the first blind to the GPU.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(l, name)     # AttributeError if the library does not export it
