@@ -99,11 +99,18 @@ def main():
         q_network=qf, q_optimizer=torch.optim.Adam(qf.parameters(), lr=3e-4),
         v_network=vf, v_optimizer=torch.optim.Adam(vf.parameters(), lr=3e-4),
         iql_tau=0.7, beta=3.0, max_steps=1_000_000, discount=0.99, tau=0.005, device=dev)
+    force_dp = os.environ.get("IQLHIP_BENCH_FORCE_DP") == "1"   # diagnostic: 1-rank process group, DP code path
+    if force_dp and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29731")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        tr._dp_world, tr._dp_group = 2, None      # take the split path; the collective runs over 1 rank
+        tr._dp_world_scale = 1
     if world > 1:
         tr.enable_data_parallel()
 
     def run(n):
-        if world > 1:
+        if world > 1 or force_dp:
             for _ in range(n):
                 tr.train_on_buffer(buf, B, seed=1234, sync=False)
         else:

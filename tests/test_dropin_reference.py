@@ -1,0 +1,86 @@
+"""Drop-in check: the reference's OWN jsrl_utils.py, imported unmodified from
+/root/reference, runs against this repo's `iql` module (sys.path order decides which `iql` the flat
+sibling import `from iql import ...` resolves to).  Host-only third-party modules that are not
+installed are stubbed exactly as tools/make_goldens.py does.  Skipped where the reference is absent
+(the GPU box): nothing of the reference travels."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference/algorithms/finetune"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def ref_jsrl():
+    import iql as ours  # this repo's drop-in (conftest put jsrl-corl_amd first on sys.path)
+
+    def stub(name, **attrs):
+        if name in sys.modules:
+            return sys.modules[name]
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    for pkg in ("gym", "gymnasium"):
+        wr = stub(pkg + ".wrappers")
+        sp = stub(pkg + ".spaces", Discrete=_Any)
+        stub(pkg, Env=_Any, wrappers=wr, spaces=sp, register_envs=lambda *a, **k: None)
+    pol = stub("stable_baselines3.sac.policies", Actor=_Any)
+    sac = stub("stable_baselines3.sac", policies=pol)
+    stub("stable_baselines3", SAC=_Any, sac=sac)
+    sys.path.append(REF)          # AFTER ours: `iql` stays ours, the sibling modules come from the reference
+    import jsrl_utils
+    assert jsrl_utils.ImplicitQLearning is ours.ImplicitQLearning
+    yield jsrl_utils, ours
+    sys.path.remove(REF)
+
+
+class Cfg:
+    device = "cpu"
+    actor_dropout = 0.0
+    iql_deterministic = False
+    vf_lr = qf_lr = actor_lr = 3e-4
+    discount, tau, beta, iql_tau = 0.99, 0.005, 3.0, 0.7
+    n_curriculum_stages, horizon_fn, no_agent_types, rolling_mean_n, tolerance = 5, "time_step", True, 5, 0.05
+    guide_heuristic_fn = None
+    offline_iterations = 123
+
+
+def test_reference_make_actor_builds_our_trainer(ref_jsrl):
+    jsrl, ours = ref_jsrl
+    tr = jsrl.make_actor(Cfg(), 17, 6, 1.0, max_steps=1000)
+    assert isinstance(tr, ours.ImplicitQLearning) and isinstance(tr.actor, ours.GaussianPolicy)
+    assert tr.actor_lr_schedule is not None and tr.total_it == 0
+    tr2 = jsrl.make_actor(Cfg(), 17, 6, 1.0)           # online learner: no LR schedule (jsrl_utils.py:351)
+    assert tr2.actor_lr_schedule is None
+    a = tr.actor.act(np.zeros(17, dtype=np.float32), "cpu")
+    assert a.shape == (6,) and np.all(np.abs(a) <= 1.0)
+
+
+def test_reference_learning_agent_handoff(ref_jsrl):
+    jsrl, ours = ref_jsrl
+    cfg = Cfg()
+    cfg.n_curriculum_stages = 1
+    guide = jsrl.make_actor(cfg, 17, 6, 1.0, max_steps=1000)
+    trainer, cfg2 = jsrl.get_learning_agent(cfg, guide, 300, 17, 6, 1.0)
+    assert trainer.total_it == cfg.offline_iterations                     # jsrl_utils.py:355
+    assert all(torch.equal(a, b) for a, b in zip(trainer.actor.parameters(), guide.actor.parameters()))
+    assert all(torch.equal(a, b) for a, b in zip(trainer.q_target.parameters(), guide.qf.parameters()))
+    assert cfg2.curriculum_stage_idx == 0 and cfg2.best_eval_score == -np.inf
+
+
+def test_reference_curriculum_logic_runs(ref_jsrl):
+    jsrl, _ = ref_jsrl
+    cfg = jsrl.prepare_finetuning(300, Cfg())
+    assert list(cfg.all_curriculum_stages) == [300, 225, 150, 75, 0]
