@@ -406,15 +406,30 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 struct RowIn {
   f32x4 h[6];       // scalar head partials: inst 0..5 x ns 0..3
   float r, d;
+  f32x4 hp[8];      // pi only: head partials of action dims 0..7 (dims >= 8 are loaded in row_finish)
+  float ac[8];      // pi only: the row's action dims 0..7
 };
 
-__device__ __forceinline__ void row_issue(const StepParams& p, int row, RowIn& in) {
+// `net` is block-uniform.  The pi inputs are issued here, with the other first-needed loads, because
+// vmcnt retires in issue order: loaded later they would queue behind the block's 96 KiB of tile loads.
+__device__ __forceinline__ void row_issue(const StepParams& p, int net, int row, RowIn& in) {
   const f32x4* h = (const f32x4*)(p.sc.heads + row * HEAD_LD);
 #pragma unroll
   for (int i = 0; i < 6; ++i) in.h[i] = h[i];
   const float* xr = p.xb + row * p.ld + 2 * p.S + p.A;
   in.r = xr[0];
   in.d = xr[1];
+  if (net == IQLHIP_NET_PI) {
+    const int A = p.A;
+    const float* arow = p.xb + row * p.ld + p.S;
+    const f32x4* hp = (const f32x4*)(p.sc.heads + p.sc.max_batch * HEAD_LD + row * A * NSPLIT);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int dd = min(j, A - 1);
+      in.hp[j] = hp[dd];
+      in.ac[j] = arow[dd];
+    }
+  }
 }
 
 __device__ __forceinline__ float sum4(const f32x4 v) { return ((v[0] + v[1]) + v[2]) + v[3]; }
@@ -469,11 +484,16 @@ __device__ __forceinline__ void row_finish(const StepParams& p, int net, int row
       // batch the loads of 8 action dims (unconditional, clamped), then do the arithmetic
       f32x4 hv[8];
       float acv[8];
+      if (d0 == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int dd = min(d0 + j, A - 1);
-        hv[j] = hp[dd];
-        acv[j] = arow[dd];
+        for (int j = 0; j < 8; ++j) { hv[j] = in.hp[j]; acv[j] = in.ac[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int dd = min(d0 + j, A - 1);
+          hv[j] = hp[dd];
+          acv[j] = arow[dd];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // inputs first, then the 96 KiB of activation tiles, which stream in under the dY arithmetic.
     const int prow = cbase + tid;
     RowIn in;
-    row_issue(p, min(prow, B - 1), in);
+    row_issue(p, net, min(prow, B - 1), in);
     float w2pre[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -808,10 +828,16 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // ---- issue every global load of the block, first-needed first (vmcnt retires in issue order)
     RowIn in;
     const int prow = min(row0 + (tid & 31), B - 1);
-    row_issue(p, prow, in);
-    // W2 rows matching this thread's H1 columns (all threads use cols 4*(tid&63)); D == 1 fast path
+    row_issue(p, net, prow, in);
+    // W2 rows matching this thread's H1 columns (all threads use cols 4*(tid&63)): row 0 for the scalar
+    // heads, rows 0..7 for the policy (issued now, ahead of the W1 stream; rows >= 8 are loaded later)
     const int j4 = tid & 63;
     const f32x4 w2v = *(const f32x4*)(w2 + 4 * j4);
+    f32x4 w2v8[8];
+    if (D > 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w2v8[j] = *(const f32x4*)(w2 + min(j, D - 1) * HID + 4 * j4);
+    }
     // H1 tile [32][256] as float4 f = tid + 256q: row f>>6, cols 4*(f&63)
     f32x4 h1v[8];
 #pragma unroll
@@ -865,8 +891,13 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         s = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int d0 = 0; d0 < D; d0 += 8) {
           f32x4 wv[8];
+          if (d0 == 0) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) wv[j] = *(const f32x4*)(w2 + min(d0 + j, D - 1) * HID + 4 * j4);
+            for (int j = 0; j < 8; ++j) wv[j] = w2v8[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = *(const f32x4*)(w2 + min(d0 + j, D - 1) * HID + 4 * j4);
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float dy = (d0 + j < D) ? dYs[rl * DYLD + min(d0 + j, D - 1)] : 0.f;
