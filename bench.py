@@ -111,8 +111,7 @@ def main():
 
     def run(n):
         if world > 1 or force_dp:
-            for _ in range(n):
-                tr.train_on_buffer(buf, B, seed=1234, sync=False)
+            tr.train_steps_dp(buf, n, B, seed=1234)
         else:
             tr.train_steps(buf, n, B, seed=1234, return_losses=False)
 

@@ -437,6 +437,48 @@ class ImplicitQLearning:
             done += k
         return losses
 
+    def train_steps_dp(self, replay_buffer, n_steps: int, batch_size: int, seed: int = 0) -> None:
+        """n_steps data-parallel steps without host syncs: every rank draws its own rows on the
+        device (one draw per chunk, rank-offset Philox stream), then per step forward+backward →
+        all_reduce(SUM) of the flat gradient over RCCL → fused Adam/Polyak (iqlhip_dp.py).  The Adam /
+        cosine-LR scalars of the whole chunk are precomputed; the loop body is three calls."""
+        self._prepare(batch_size)
+        if not getattr(replay_buffer, "_gpu", False):
+            raise ValueError("train_steps_dp needs a ReplayBuffer that lives on the GPU")
+        size = replay_buffer._index_bound()
+        lib = hb.lib()
+        world = self._dp_world
+        rank = torch.distributed.get_rank(self._dp_group) if world > 1 else 0
+        S, A = self._S, self._A
+        base, ld = replay_buffer._rows.data_ptr(), replay_buffer._ld
+        flat = self._dp_flat()
+        fptr = flat.data_ptr()
+        stream = self._stream()
+        done = 0
+        while done < n_steps:
+            k = min(1000, n_steps - done)
+            idx = getattr(self, "_idx_chunk", None)
+            if idx is None or idx.numel() < k * batch_size:
+                idx = torch.empty(1000 * batch_size, dtype=torch.int64, device=self._dev)
+                self._idx_chunk = idx
+            hb.check(lib.iqlhip_draw_indices(idx.data_ptr(), k * batch_size, size, dp.rank_seed(seed, rank),
+                                             int(self.total_it) * ((batch_size + 1) // 2), stream))
+            tab = self._scalar_table(k, dp.inv_batch(batch_size, world))
+            rows = tab.ctypes.data
+            b = hb.Batch(base, base + 4 * S, base + 4 * (2 * S + A), base + 4 * (S + A), base + 4 * (2 * S + A + 1),
+                         ld, ld, ld, ld, ld, idx.data_ptr(), batch_size)
+            bref = C.byref(b)
+            ip = idx.data_ptr()
+            for i in range(k):
+                b.idx_dev = ip + 8 * i * batch_size
+                sc = C.cast(rows + 48 * i, C.POINTER(hb.StepScalars))
+                hb.check(lib.iqlhip_forward_backward(self._ctx, bref, sc, fptr, stream))
+                if world > 1:
+                    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self._dp_group)
+                hb.check(lib.iqlhip_apply_update(self._ctx, fptr, sc, stream))
+            self.total_it += k
+            done += k
+
     def train_on_buffer(self, replay_buffer, batch_size: int, seed: int = 0, sync: bool = False):
         """One step on rows drawn ON THE DEVICE from `replay_buffer` (no host index draw, no
         host sync unless `sync`).  Data-parallel aware: each rank draws its own rows (seed is

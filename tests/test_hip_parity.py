@@ -236,3 +236,27 @@ def test_device_index_draw_is_uniform():
     assert c.sum() == n and c.min() > 0
     chi2 = float(((c - n / size) ** 2 / (n / size)).sum())
     assert 800 < chi2 < 1250, chi2      # 999 dof: mean 999, sd ~45
+
+
+def test_dp_multi_step_loop_world1_equals_graph_steps():
+    """train_steps_dp (the loop bench.py runs under torch.distributed) at world = 1 walks the same
+    device index stream as train_steps and lands on the same parameters bitwise."""
+    import iql
+    build, _, _, read_params, _, _ = _hip()
+    S, A, N, B, K = 17, 6, 5000, 256, 5
+    params = synth.synth_params(S, A, seed=31)
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    data = synth.synth_transitions(N, S, A, seed=32)
+    buf = iql.ReplayBuffer(S, A, N, "cuda")
+    buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    g = build(params, S, A, True, hyper, lrs, 1000)
+    g.train_steps(buf, K, B, seed=5, return_losses=False)
+    d = build(params, S, A, True, hyper, lrs, 1000)
+    d.train_steps_dp(buf, K, B, seed=5)
+    torch.cuda.synchronize()
+    assert d.total_it == K
+    pa, pb = read_params(g), read_params(d)
+    for n in pa:
+        for kk in pa[n]:
+            assert np.array_equal(pa[n][kk], pb[n][kk]), (n, kk)
