@@ -122,6 +122,15 @@ int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper, int device
 int iqlhip_destroy(iqlhip_ctx* ctx);
 int iqlhip_set_hyper(iqlhip_ctx* ctx, const iqlhip_hyper* hyper);
 
+/* Actor dropout (GaussianPolicy/DeterministicPolicy(..., dropout=p) -> nn.Dropout(p) after each hidden ReLU,
+ * iql.py:331-333, active while the actor is in train mode): p in [0,1), 0 = off.  Keep-masks are drawn on
+ * the device (Philox4x32-10 keyed by `seed` and a per-step counter). */
+int iqlhip_set_dropout(iqlhip_ctx* ctx, float p, uint64_t seed);
+/* Tests: inject keep-bits for the next steps instead of drawing them ([rows][8] uint32 per layer, bit j of
+ * word w = hidden unit 32w + j); cleared by the next iqlhip_set_dropout. */
+int iqlhip_debug_write_masks(iqlhip_ctx* ctx, const uint32_t* keep0_host, const uint32_t* keep1_host, int32_t rows,
+                             void* stream);
+
 /* Bind the caller-owned arenas: params (n_params), target (n_target; the
  * deepcopy q_target of iql.py:461), Adam exp_avg / exp_avg_sq (n_params each). */
 int iqlhip_bind(iqlhip_ctx* ctx, float* params_dev, float* target_dev, float* exp_avg_dev, float* exp_avg_sq_dev);

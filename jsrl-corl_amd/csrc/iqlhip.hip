@@ -34,8 +34,9 @@ struct GraphKey {
   int64_t ld = 0;
   int32_t B = 0, K = 0;
   float* params = nullptr;
+  float drop_p = 0.f;
   bool operator==(const GraphKey& o) const {
-    return rows == o.rows && ld == o.ld && B == o.B && K == o.K && params == o.params;
+    return rows == o.rows && ld == o.ld && B == o.B && K == o.K && params == o.params && drop_p == o.drop_p;
   }
 };
 
@@ -51,6 +52,11 @@ struct iqlhip_ctx {
   float* flat_tmp = nullptr;          // n_params + 4 (debug "grads")
   float* xb = nullptr;                // compact batch [max_batch][row_ld]: rows [s | a | s' | r | d | pad]
   int64_t row_ld = 0;
+  // actor dropout
+  unsigned* drop_bits = nullptr;      // [2][max_batch][8] keep-bits
+  float drop_p = 0.f;
+  unsigned long long drop_seed = 0, drop_step = 0;
+  bool drop_inject = false;           // tests: masks were written by iqlhip_debug_write_masks, do not regenerate
   float* loss_ring = nullptr;         // [ring_cap][4]
   int ring_cap = 0;
   long long* idx_chunk = nullptr;     // [K_max * max_batch]
@@ -150,6 +156,8 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   HIPCHK(dalloc(&c->sc.heads, (size_t)MB * HEAD_LD + (size_t)NSPLIT * MB * A));
   c->row_ld = iqlhip_row_stride(dims->state_dim, A);
   HIPCHK(dalloc(&c->xb, (size_t)MB * c->row_ld));
+  HIPCHK(hipMalloc((void**)&c->drop_bits, (size_t)2 * MB * 8 * sizeof(unsigned)));
+  HIPCHK(hipMemset(c->drop_bits, 0xFF, (size_t)2 * MB * 8 * sizeof(unsigned)));
   HIPCHK(dalloc(&c->sc.slab_a, (size_t)c->n_chunk_max * c->L.n_params));
   size_t sb = 0;
   for (int n = 0; n < 4; ++n) {
@@ -175,7 +183,7 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   const int kq = dims->state_dim + dims->action_dim;
   const int ks_ = dims->state_dim;   // V / pi layer-0 width; Q nets use kq
   const int w0_lds_k = (kq <= W0_LDS_MAX_K) ? kq : ((ks_ <= W0_LDS_MAX_K) ? ks_ : 0);
-  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * 132 + IQLHIP_MAX_ACTION * 65 + 16 +
+  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * 132 + IQLHIP_MAX_ACTION * 65 + 512 + 16 +
                         HID * w0_lds_k) * sizeof(float);
   const int dyld = ((A + 15) & ~15) + 1;
   const size_t lds_a = (size_t)(4 * 32 * T64_LD + 2 * CHUNK_ROWS * dyld + 32 * 32 + 64) * sizeof(float);
@@ -204,7 +212,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
-                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb};
+                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb, c->drop_bits};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
   return IQLHIP_OK;
@@ -214,6 +222,28 @@ extern "C" int iqlhip_set_hyper(iqlhip_ctx* c, const iqlhip_hyper* h) {
   if (!c || !h) return fail(IQLHIP_EINVAL, "NULL argument");
   c->hyper = *h;
   drop_graph(c);
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_set_dropout(iqlhip_ctx* c, float p, uint64_t seed) {
+  if (!c) return fail(IQLHIP_EINVAL, "NULL ctx");
+  if (!(p >= 0.f && p < 1.f)) return fail(IQLHIP_EINVAL, "dropout probability must be in [0,1)");
+  c->drop_p = p;
+  c->drop_seed = seed;
+  c->drop_inject = false;
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_debug_write_masks(iqlhip_ctx* c, const uint32_t* keep0, const uint32_t* keep1, int32_t rows,
+                                        void* stream) {
+  if (!c || !keep0 || !keep1) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (rows < 1 || rows > c->dims.max_batch) return fail(IQLHIP_EINVAL, "rows outside [1,max_batch]");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nb = (size_t)rows * 8 * sizeof(unsigned);
+  HIPCHK(hipMemcpyAsync(c->drop_bits, keep0, nb, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->drop_bits + (size_t)c->dims.max_batch * 8, keep1, nb, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  c->drop_inject = true;
   return IQLHIP_OK;
 }
 
@@ -314,6 +344,8 @@ static StepParams make_step(const iqlhip_ctx* c, int rows, float inv_batch) {
   p.policy = c->dims.policy;
   p.inv_batch = inv_batch;
   p.n_params = L.n_params;
+  p.drop_bits = (c->drop_p > 0.f) ? c->drop_bits : nullptr;
+  p.drop_scale = (c->drop_p > 0.f) ? 1.f / (1.f - c->drop_p) : 1.f;
   return p;
 }
 
@@ -338,6 +370,8 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.sched_idx = 0;
   u.n_upd_blocks = (int)((c->L.n_params / 4 + 255) / 256);
   u.g_rows = nullptr; u.g_ld = c->row_ld; u.g_idx = nullptr; u.g_xb = c->xb; u.g_n = 0;
+  u.n_gather_blocks = 0;
+  u.d_bits = nullptr; u.d_n_words = 2 * c->dims.max_batch * 8; u.d_thresh = 0; u.d_hdr = c->hdr; u.d_k = 0;
   return u;
 }
 
@@ -351,9 +385,23 @@ static void launch_bwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st)
   const int per_net = 32 * n_chunk + 4 * n_rt;
   hipLaunchKernelGGL(iql_bwd_kernel, dim3(8 * ((per_net + 1) / 2)), dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
 }
-static void launch_upd(const iqlhip_ctx* c, const UpdParams& u, hipStream_t st) {
+static unsigned drop_thresh(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+}
+
+static void launch_dropmask(const iqlhip_ctx* c, unsigned long long seed, unsigned long long step,
+                            const unsigned long long* hdr, int k, hipStream_t st) {
+  const int n_words = 2 * c->dims.max_batch * 8;
+  hipLaunchKernelGGL(iql_dropmask_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, c->drop_bits, n_words,
+                     drop_thresh(c->drop_p), seed, step, hdr, k);
+}
+
+static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
   int nb = u.n_upd_blocks;
-  if (u.g_idx) nb += (u.g_n * (int)(u.g_ld / 4) + 255) / 256;   // gather blocks for the next step's rows
+  u.n_gather_blocks = u.g_idx ? (u.g_n * (int)(u.g_ld / 4) + 255) / 256 : 0;   // next step's rows
+  nb += u.n_gather_blocks;
+  if (u.d_bits) nb += (u.d_n_words + 255) / 256;                               // next step's dropout keep-bits
   if (u.sched) hipLaunchKernelGGL(iql_update_kernel<true>, dim3(nb), dim3(256), 0, st, u);
   else hipLaunchKernelGGL(iql_update_kernel<false>, dim3(nb), dim3(256), 0, st, u);
 }
@@ -405,6 +453,7 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   hipStream_t st = (hipStream_t)stream;
   rc = stage_batch(c, b, st);
   if (rc) return rc;
+  if (c->drop_p > 0.f && !c->drop_inject) launch_dropmask(c, c->drop_seed, c->drop_step++, nullptr, 0, st);
   StepParams p = make_step(c, b->rows, sc->inv_batch);
   UpdParams u = make_upd(c, sc, b->rows, nullptr);
   hipEvent_t* ev = nullptr;
@@ -434,6 +483,7 @@ extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, con
   hipStream_t st = (hipStream_t)stream;
   rc = stage_batch(c, b, st);
   if (rc) return rc;
+  if (c->drop_p > 0.f && !c->drop_inject) launch_dropmask(c, c->drop_seed, c->drop_step++, nullptr, 0, st);
   StepParams p = make_step(c, b->rows, sc->inv_batch);
   UpdParams u = make_upd(c, sc, b->rows, nullptr);
   launch_fwd(c, p, st);
@@ -497,7 +547,7 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
   if (((uintptr_t)rows_dev) & 15) return fail(IQLHIP_EINVAL, "packed rows must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   GraphKey key;
-  key.rows = rows_dev; key.ld = ld; key.B = B; key.K = K; key.params = c->params;
+  key.rows = rows_dev; key.ld = ld; key.B = B; key.K = K; key.params = c->params; key.drop_p = c->drop_p;
   hipGraphExec_t gexec = nullptr;
   for (auto& g : c->graphs)
     if (g.key == key) { gexec = g.exec; g.stamp = ++c->graph_clock; }
@@ -518,6 +568,7 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
                          0ull, 0ull, (const unsigned long long*)c->hdr);
     }
     launch_gather(c, rows_dev, c->idx_chunk, B, cs);   // rows of step 0; step k+1's ride on update k
+    if (c->drop_p > 0.f) launch_dropmask(c, 0, 0, c->hdr, 0, cs);   // keep-bits of step 0 (seed/step0 from hdr)
     for (int k = 0; k < K; ++k) {
       StepParams p = make_step(c, B, sc[0].inv_batch);
       UpdParams u = make_upd(c, &sc[0], B, nullptr);
@@ -525,7 +576,10 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
       u.sched_idx = k;
       u.loss_ring = c->loss_ring;
       u.ring_slot = k;
-      if (k + 1 < K) { u.g_rows = rows_dev; u.g_idx = c->idx_chunk + (long long)(k + 1) * B; u.g_n = B; }
+      if (k + 1 < K) {
+        u.g_rows = rows_dev; u.g_idx = c->idx_chunk + (long long)(k + 1) * B; u.g_n = B;
+        if (c->drop_p > 0.f) { u.d_bits = c->drop_bits; u.d_thresh = drop_thresh(c->drop_p); u.d_k = k + 1; }
+      }
       launch_fwd(c, p, cs);
       launch_bwd(c, p, cs);
       launch_upd(c, u, cs);
@@ -536,7 +590,9 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
     HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     c->graphs.push_back({key, graph, gexec, ++c->graph_clock});
   }
-  unsigned long long hdr[4] = {(unsigned long long)size, (unsigned long long)seed, (unsigned long long)stream_offset, 0};
+  unsigned long long hdr[4] = {(unsigned long long)size, (unsigned long long)seed, (unsigned long long)stream_offset,
+                               c->drop_step};
+  c->drop_step += (unsigned long long)K;
   HIPCHK(hipMemcpyAsync(c->hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(c->sched, sc, (size_t)K * sizeof(iqlhip_step_scalars), hipMemcpyHostToDevice, st));
   hipEvent_t* ev = nullptr;
@@ -637,6 +693,7 @@ extern "C" int iqlhip_debug_read(iqlhip_ctx* c, const char* name, float* host_ou
   else if (!strcmp(name, "h1")) { src = c->sc.h1; n = (int64_t)4 * MB * HID; }
   else if (!strcmp(name, "heads")) { src = c->sc.heads; n = (int64_t)MB * HEAD_LD + (int64_t)NSPLIT * MB * c->dims.action_dim; }
   else if (!strcmp(name, "loss_parts")) { src = c->sc.loss_parts; n = 4 * 64; }
+  else if (!strcmp(name, "drop_bits")) { src = (const float*)c->drop_bits; n = (int64_t)2 * MB * 8; }
   else if (!strcmp(name, "stamps")) {   // 64-bit stamps returned as pairs of 32-bit words
     if (!c->stamps) return fail(IQLHIP_EINVAL, "library built without -DIQL_STAMPS");
     src = (const float*)c->stamps; n = 4096 * 16 * 2;

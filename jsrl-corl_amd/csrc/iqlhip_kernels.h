@@ -93,6 +93,10 @@ struct StepParams {
   int S, A, policy;
   float inv_batch;
   long long n_params;
+  // actor dropout (nn.Dropout(p) after each hidden ReLU of the policy MLP, iql.py:331-333): keep-bits
+  // [2 layers][max_batch][8 words] (bit j of word w = unit 32w + j), scale = 1/(1-p); null when off
+  const unsigned* drop_bits;
+  float drop_scale;
 };
 
 // Force kernel-argument fields into SGPRs NOW.  hipcc sinks each s_load next to its first use, which
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   float* H1s = H0s + RT_ROWS * H0_LD;        // [32][T64_LD]
   float* Xr = H1s + RT_ROWS * T64_LD;        // [32][ld]  packed rows of this tile
   float* W2s = Xr + RT_ROWS * 132;           // [D][64] head weights of this column slice, then b2[D]
-  float* W0s = W2s + IQLHIP_MAX_ACTION * 65;   // [256*k0] flat copy of layer-0 weights (when w0_lds); 16-B aligned
+  unsigned* Mk = (unsigned*)(W2s + IQLHIP_MAX_ACTION * 65);   // [2][32][8] dropout keep-bits of the tile
+  float* W0s = W2s + IQLHIP_MAX_ACTION * 65 + 512;   // [256*k0] flat copy of layer-0 weights (when w0_lds); 16-B aligned
   // (no integer casts on LDS pointers: they would demote every access to a flat load, and a flat load
   //  waits vmcnt(0) — it would drain the W1 stream that is meant to stay in flight under layer 0)
 
@@ -178,6 +183,14 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) bias0[ct] = *(const f32x4*)(np.b0 + wave * 64 + ct * 16 + 4 * g);
   const f32x4 bias1 = *(const f32x4*)(np.b1 + ns * 64 + wave * 16 + 4 * g);
+  // (b2) dropout keep-bits of this row tile (policy instance only): thread -> (row tid >> 3, word tid & 7)
+  const bool drop = (inst == 6) && (p.drop_bits != nullptr);
+  unsigned mk0 = 0xFFFFFFFFu, mk1 = 0xFFFFFFFFu;
+  if (drop) {
+    const int mrow = min(row0 + (tid >> 3), B - 1);
+    mk0 = p.drop_bits[mrow * 8 + (tid & 7)];
+    mk1 = p.drop_bits[(MB + mrow) * 8 + (tid & 7)];
+  }
   // (c) layer-0 weights: flat float4 copy of 64*k0 float4 (thread handles tid + 256 j); 8 loads cover k0 <= 32
   const int n_w0v = 64 * k0;
   f32x4 w0v[16];
@@ -206,6 +219,8 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     if (e < D * 16) *(f32x4*)(W2s + 4 * e) = w2pre[q];
   }
   if (tid < D) W2s[D * 64 + tid] = b2v;
+  Mk[tid] = mk0;
+  Mk[256 + tid] = mk1;
   if (w0_lds) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -318,6 +333,11 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
         f32x4 h;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) h[reg] = fmaxf(acc[rtile][ct][reg] + bias0[ct][reg], 0.f);
+        if (drop) {   // units wave*64 + ct*16 + 4g .. +3 of row rtile*16 + l15
+          const unsigned bits = Mk[(rtile * 16 + l15) * 8 + wave * 2 + (ct >> 1)] >> ((ct & 1) * 16 + 4 * g);
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) h[reg] = ((bits >> reg) & 1u) ? h[reg] * p.drop_scale : 0.f;
+        }
         *(f32x4*)(H0s + (rtile * 16 + l15) * H0_LD + wave * 64 + ct * 16 + 4 * g) = h;
       }
     }
@@ -357,6 +377,15 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     for (int reg = 0; reg < 4; ++reg) {
       h0[reg] = fmaxf(acc0[reg] + bias1[reg], 0.f);
       h1[reg] = fmaxf(acc1[reg] + bias1[reg], 0.f);
+    }
+    if (drop) {   // hidden-1 units ns*64 + wave*16 + 4g .. +3 of rows l15 and 16 + l15
+      const int word = ns * 2 + (wave >> 1), sh = (wave & 1) * 16 + 4 * g;
+      const unsigned ba = Mk[256 + l15 * 8 + word] >> sh, bb_ = Mk[256 + (16 + l15) * 8 + word] >> sh;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        h0[reg] = ((ba >> reg) & 1u) ? h0[reg] * p.drop_scale : 0.f;
+        h1[reg] = ((bb_ >> reg) & 1u) ? h1[reg] * p.drop_scale : 0.f;
+      }
     }
     *(f32x4*)(H1s + l15 * T64_LD + wave * 16 + 4 * g) = h0;
     *(f32x4*)(H1s + (16 + l15) * T64_LD + wave * 16 + 4 * g) = h1;
@@ -561,6 +590,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   const float* w2 = np.w2;
   const float* H1g = p.sc.h1 + net * MB * HID;
   const float* H0g = p.sc.h0 + net * MB * HID;
+  // dropout: the saved activations are post-dropout, so (h > 0) already encodes relu AND keep; the chain
+  // rule only adds the 1/(1-p) multiplier
+  const float dscale = (net == IQLHIP_NET_PI && p.drop_bits != nullptr) ? p.drop_scale : 1.f;
   {
     const float* xb_ = p.xb; const float* hd_ = p.sc.heads; float* sa_ = p.sc.slab_a; float* sb_ = p.sc.slab_b;
     const int ld_ = p.ld, S_ = p.S, A_ = p.A, pol_ = p.policy, k0_ = np.k0;
@@ -678,8 +710,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const float dy = dYs[(rbase + ks) * DYLD];
-        av[ks][0] = (hh[ks][0] > 0.f) ? dy * w2a : 0.f;
-        av[ks][1] = (hh[ks][1] > 0.f) ? dy * w2b : 0.f;
+        av[ks][0] = (hh[ks][0] > 0.f) ? dy * w2a * dscale : 0.f;
+        av[ks][1] = (hh[ks][1] > 0.f) ? dy * w2b * dscale : 0.f;
         if (extras) {
           dw2a[0] = fmaf(dy, hh[ks][0], dw2a[0]);
           dw2a[1] = fmaf(dy, hh[ks][1], dw2a[1]);
@@ -699,8 +731,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       }
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        av[ks][0] = (hh[ks][0] > 0.f) ? av[ks][0] : 0.f;
-        av[ks][1] = (hh[ks][1] > 0.f) ? av[ks][1] : 0.f;
+        av[ks][0] = (hh[ks][0] > 0.f) ? av[ks][0] * dscale : 0.f;
+        av[ks][1] = (hh[ks][1] > 0.f) ? av[ks][1] * dscale : 0.f;
       }
     }
     if (extras) {
@@ -907,7 +939,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       }
       f32x4 out;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] : 0.f;
+      for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
       *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
     }
     __syncthreads();
@@ -958,7 +990,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + w * 32 * T64_LD + rl * T64_LD + 4 * i4);
       f32x4 out;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[e] = (h0v[q][e] > 0.f) ? s[e] : 0.f;   // rows >= B carry s = 0
+      for (int e = 0; e < 4; ++e) out[e] = (h0v[q][e] > 0.f) ? s[e] * dscale : 0.f;   // rows >= B carry s = 0
       *(f32x4*)(dH0s + rl * T64_LD + 4 * i4) = out;
     }
     __syncthreads();
@@ -1049,6 +1081,13 @@ struct UpdParams {
   const long long* g_idx;   // nullable: no gather blocks
   float* g_xb;
   int g_n;
+  // next step's dropout keep-bits: further extra blocks (after the gather blocks)
+  int n_gather_blocks;
+  unsigned* d_bits;         // nullable: no mask blocks
+  int d_n_words;
+  unsigned d_thresh;
+  const unsigned long long* d_hdr;
+  int d_k;
 };
 
 __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
@@ -1097,6 +1136,46 @@ __device__ __forceinline__ void loss_words(const UpdParams& u, float out[4]) {
   out[3] = s[3];   // sum_r w bc
 }
 
+// Philox4x32-10 (Salmon et al. 2011).
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// Dropout keep-bits for one step: word w (of n_words = 2 * max_batch * 8) gets 32 independent Bernoulli(1-p)
+// bits: keep iff u32 >= thresh (thresh = p * 2^32).  Stream: key = seed, counter = (word, call, step).
+__device__ __forceinline__ void dropmask_words(unsigned* bits, int n_words, unsigned thresh, unsigned long long seed,
+                                               unsigned long long step, int first, int stride) {
+  for (int w = first; w < n_words; w += stride) {
+    unsigned word = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t c[4] = {(uint32_t)w, (uint32_t)j | 0x44524F50u /* "DROP" */, (uint32_t)step, (uint32_t)(step >> 32)};
+      philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) word |= (c[q] >= thresh ? 1u : 0u) << (4 * j + q);
+    }
+    bits[w] = word;
+  }
+}
+
+// `hdr` (nullable): device words {size, seed, offset, step0}: a captured graph is replayed with new values.
+__global__ __launch_bounds__(256) void iql_dropmask_kernel(unsigned* bits, int n_words, unsigned thresh,
+                                                           unsigned long long seed, unsigned long long step,
+                                                           const unsigned long long* hdr, int k) {
+  if (hdr) { seed = hdr[1] ^ 0x5EEDD120ull; step = hdr[3] + (unsigned long long)k; }
+  dropmask_words(bits, n_words, thresh, seed, step, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
 // rows[idx[r]] -> xb[r], r < n: one float4 per thread-iteration (rows are 16-B aligned, ld % 4 == 0)
 __device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld, const long long* idx, float* xb,
                                                  int n, int first, int stride) {
@@ -1137,10 +1216,16 @@ __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, floa
 template <bool FROM_TABLE>
 __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
   if ((int)blockIdx.x >= u.n_upd_blocks) {
-    // gather blocks: stage the next step's rows while the optimizer blocks run
+    // extra blocks: stage the next step's rows (and dropout keep-bits) while the optimizer blocks run
     const int gb = (int)blockIdx.x - u.n_upd_blocks;
-    const int ngb = (int)gridDim.x - u.n_upd_blocks;
-    gather_rows_flat(u.g_rows, u.g_ld, u.g_idx, u.g_xb, u.g_n, gb * 256 + threadIdx.x, ngb * 256);
+    if (gb < u.n_gather_blocks) {
+      gather_rows_flat(u.g_rows, u.g_ld, u.g_idx, u.g_xb, u.g_n, gb * 256 + threadIdx.x, u.n_gather_blocks * 256);
+    } else {
+      const int mb = gb - u.n_gather_blocks;
+      const int nmb = (int)gridDim.x - u.n_upd_blocks - u.n_gather_blocks;
+      dropmask_words(u.d_bits, u.d_n_words, u.d_thresh, u.d_hdr[1] ^ 0x5EEDD120ull,
+                     u.d_hdr[3] + (unsigned long long)u.d_k, mb * 256 + threadIdx.x, nmb * 256);
+    }
     return;
   }
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -1262,21 +1347,7 @@ __global__ void iql_rows_gather_kernel(const float* rows, long long ld, int S, i
   }
 }
 
-// Philox4x32-10 (Salmon et al. 2011), counter = (offset + i/2), key = seed.
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-
+// Index draw: Philox4x32-10, counter = (offset + i/2), key = seed.
 // idx[i] uniform over [0,size): 64 random bits, multiply-high (bias <= size / 2^64).
 // `hdr` (nullable) = device words {size, seed, offset} so that a captured graph can be replayed
 // with new values.

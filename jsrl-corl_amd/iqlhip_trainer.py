@@ -108,8 +108,8 @@ class ImplicitQLearning:
             raise NotImplementedError("network shapes are not the IQL TwinQ / ValueFunction / policy MLP family")
         if hid != hb.IQLHIP_HIDDEN:
             raise NotImplementedError(f"iqlhip kernels are tiled for hidden_dim={hb.IQLHIP_HIDDEN}, got {hid}")
-        if dropout_p(self.actor) > 0.0:
-            raise NotImplementedError("actor dropout > 0 is not implemented in the HIP step yet")
+        if dropout_p(self.vf) > 0.0 or dropout_p(self.qf) > 0.0:
+            raise NotImplementedError("dropout is implemented for the actor only (the reference has none elsewhere)")
         gaussian = "log_std" in nets["pi"]
         if not gaussian and not isinstance(self.actor, DeterministicPolicy) and not hasattr(self.actor, "net"):
             raise NotImplementedError("unknown policy class")
@@ -153,6 +153,7 @@ class ImplicitQLearning:
         hb.check(hb.lib().iqlhip_create(C.byref(d), C.byref(h), dev.index, C.byref(ctx)))
         self._ctx = ctx
         self._hyper_sent = self._hyper_tuple()
+        self._dropout_sent = 0.0
         self._max_batch = max_batch
         hb.check(hb.lib().iqlhip_bind(self._ctx, self._params_arena.data_ptr(), self._target_arena.data_ptr(),
                                       self._m_arena.data_ptr(), self._v_arena.data_ptr()))
@@ -287,6 +288,12 @@ class ImplicitQLearning:
             h = self._hyper_struct()
             hb.check(hb.lib().iqlhip_set_hyper(self._ctx, C.byref(h)))
             self._hyper_sent = self._hyper_tuple()
+        # actor dropout follows the module's mode, like nn.Dropout (active in train(), off in eval())
+        p_eff = float(dropout_p(self.actor)) if self.actor.training else 0.0
+        if p_eff != self._dropout_sent:
+            rank = torch.distributed.get_rank(self._dp_group) if self._dp_world > 1 else 0
+            hb.check(hb.lib().iqlhip_set_dropout(self._ctx, p_eff, dp.rank_seed(torch.initial_seed(), rank)))
+            self._dropout_sent = p_eff
 
     def _stream(self):
         return torch.cuda.current_stream(self._dev).cuda_stream
@@ -597,6 +604,15 @@ class ImplicitQLearning:
         out = C.c_float(0)
         hb.check(hb.lib().iqlhip_debug_time_kernel(self._ctx, C.byref(b), which, repeat, C.byref(out), self._stream()))
         return float(out.value)
+
+    def inject_dropout_masks(self, keep0: np.ndarray, keep1: np.ndarray) -> None:
+        """Tests: use these keep-masks (bool [rows,256] per layer) for the following steps instead of device draws."""
+        from synth import pack_keep_bits
+        self._prepare(keep0.shape[0])
+        b0 = np.ascontiguousarray(pack_keep_bits(keep0))
+        b1 = np.ascontiguousarray(pack_keep_bits(keep1))
+        hb.check(hb.lib().iqlhip_debug_write_masks(self._ctx, b0.ctypes.data, b1.ctypes.data, keep0.shape[0],
+                                                   self._stream()))
 
     def debug_read(self, name: str) -> np.ndarray:
         self._require_gpu()

@@ -91,3 +91,16 @@ def synth_params(state_dim: int, action_dim: int, seed: int = 0, gaussian: bool 
 
 def clone_params(p):
     return {n: {k: v.copy() for k, v in t.items()} for n, t in p.items()}
+
+
+def synth_dropout_keep(n_rows: int, p: float, seed: int = 0, hidden: int = HIDDEN):
+    """Two keep-masks [n_rows, hidden] (bool) for the actor's two Dropout(p) layers (tests: mask injection)."""
+    rng = np.random.default_rng(seed + 104729)
+    return rng.random((n_rows, hidden)) >= p, rng.random((n_rows, hidden)) >= p
+
+
+def pack_keep_bits(keep: np.ndarray) -> np.ndarray:
+    """bool [rows, 256] -> uint32 [rows, 8]; bit j of word w = unit 32*w + j (the layout libiqlhip uses)."""
+    rows, h = keep.shape
+    k = keep.reshape(rows, h // 32, 32).astype(np.uint64)
+    return (k << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32)

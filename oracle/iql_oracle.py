@@ -41,23 +41,35 @@ NETS = ("vf", "q1", "q2", "pi")
 GROUP_OF = {"vf": "v", "q1": "q", "q2": "q", "pi": "pi"}
 
 
-def mlp_forward(p: Dict[str, np.ndarray], x: np.ndarray):
-    """Returns (out[B,d_out], h0[B,H], h1[B,H]); weights are [out,in]."""
+def mlp_forward(p: Dict[str, np.ndarray], x: np.ndarray, masks=None):
+    """Returns (out[B,d_out], h0[B,H], h1[B,H]); weights are [out,in].
+
+    masks = (m0, m1): dropout multipliers of the two hidden activations (0 or 1/(1-p), as
+    torch.nn.Dropout applies them after each ReLU of the actor, iql.py:331-333); h0/h1 are returned
+    POST-dropout, which is what the next layer and the backward pass consume."""
     h0 = np.maximum(x @ p["w0"].T + p["b0"], 0)
+    if masks is not None:
+        h0 = h0 * masks[0].astype(h0.dtype)
     h1 = np.maximum(h0 @ p["w1"].T + p["b1"], 0)
+    if masks is not None:
+        h1 = h1 * masks[1].astype(h1.dtype)
     out = h1 @ p["w2"].T + p["b2"]
     return out, h0, h1
 
 
-def mlp_backward(p: Dict[str, np.ndarray], x, h0, h1, dout):
-    """dout[B,d_out] -> grads dict for w0,b0,w1,b1,w2,b2 (ReLU mask = activation > 0)."""
+def mlp_backward(p: Dict[str, np.ndarray], x, h0, h1, dout, masks=None):
+    """dout[B,d_out] -> grads dict for w0,b0,w1,b1,w2,b2 (ReLU mask = activation > 0).
+    With dropout, h0/h1 are post-dropout and the chain rule carries the same multipliers."""
     g = {}
+    m0 = 1 if masks is None else masks[0].astype(h0.dtype)
+    m1 = 1 if masks is None else masks[1].astype(h1.dtype)
     g["w2"] = dout.T @ h1
     g["b2"] = dout.sum(0)
-    dh1 = (dout @ p["w2"]) * (h1 > 0)
+    # pre-activation sign: h1_post = relu(pre)*m1, so (pre > 0) == (h1_post > 0) wherever m1 != 0
+    dh1 = (dout @ p["w2"]) * m1 * (h1 > 0)
     g["w1"] = dh1.T @ h0
     g["b1"] = dh1.sum(0)
-    dh0 = (dh1 @ p["w1"]) * (h0 > 0)
+    dh0 = (dh1 @ p["w1"]) * m0 * (h0 > 0)
     g["w0"] = dh0.T @ x
     g["b0"] = dh0.sum(0)
     return g
@@ -67,7 +79,8 @@ def q_input(s, a):
     return np.concatenate([s, a], axis=1)
 
 
-def iql_losses_and_grads(params, batch, hyper, dtype=np.float32, grad_scale_rows: Optional[int] = None):
+def iql_losses_and_grads(params, batch, hyper, dtype=np.float32, grad_scale_rows: Optional[int] = None,
+                         actor_masks=None):
     """All forwards + closed-form gradients from PRE-step parameters.
 
     batch: dict s[B,S] a[B,A] r[B] ns[B,S] d[B].  hyper: iql_tau, beta, discount,
@@ -97,7 +110,7 @@ def iql_losses_and_grads(params, batch, hyper, dtype=np.float32, grad_scale_rows
     q2, q2_h0, q2_h1 = mlp_forward(P["q2"], sa)
     q1 = q1[:, 0]
     q2 = q2[:, 0]
-    pre, pi_h0, pi_h1 = mlp_forward(P["pi"], s)
+    pre, pi_h0, pi_h1 = mlp_forward(P["pi"], s, masks=actor_masks)
     mu = np.tanh(pre)
 
     # value loss (iql.py:489-490, 301-302)
@@ -141,7 +154,7 @@ def iql_losses_and_grads(params, batch, hyper, dtype=np.float32, grad_scale_rows
         "vf": mlp_backward(P["vf"], s, v_h0, v_h1, dv[:, None]),
         "q1": mlp_backward(P["q1"], sa, q1_h0, q1_h1, dq1[:, None]),
         "q2": mlp_backward(P["q2"], sa, q2_h0, q2_h1, dq2[:, None]),
-        "pi": mlp_backward(P["pi"], s, pi_h0, pi_h1, dpre),
+        "pi": mlp_backward(P["pi"], s, pi_h0, pi_h1, dpre, masks=actor_masks),
     }
     grads["pi"].update(g_pi_extra)
     return {
@@ -188,14 +201,14 @@ def new_opt_state(params):
     }
 
 
-def iql_step(params, opt, batch, hyper, lrs, dtype=np.float32, grads_override=None):
+def iql_step(params, opt, batch, hyper, lrs, dtype=np.float32, grads_override=None, actor_masks=None):
     """One full reference step.  Mutates nothing; returns (new_params, new_opt, info).
 
     lrs: {"v","q","pi"} learning rates USED by this step (the cosine schedule
     is stepped by the caller AFTER the actor update, iql.py:539-540).
     """
     f = dtype
-    info = iql_losses_and_grads(params, batch, hyper, dtype=dtype)
+    info = iql_losses_and_grads(params, batch, hyper, dtype=dtype, actor_masks=actor_masks)
     grads = grads_override if grads_override is not None else info["grads"]
     newp = {n: {k: v.astype(f) for k, v in t.items()} for n, t in params.items()}
     newo = {"m": {}, "v": {}, "t": dict(opt["t"])}

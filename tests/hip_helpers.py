@@ -31,10 +31,10 @@ def _read_mlp(mod):
     return out
 
 
-def build_hip_trainer(params, S, A, gaussian, hyper, lrs, max_steps, device="cuda"):
+def build_hip_trainer(params, S, A, gaussian, hyper, lrs, max_steps, device="cuda", dropout=0.0):
     qf = iql.TwinQ(S, A)
     vf = iql.ValueFunction(S)
-    actor = (iql.GaussianPolicy if gaussian else iql.DeterministicPolicy)(S, A, 1.0)
+    actor = (iql.GaussianPolicy if gaussian else iql.DeterministicPolicy)(S, A, 1.0, dropout=dropout)
     _load_mlp(vf.v, params["vf"])
     _load_mlp(qf.q1, params["q1"])
     _load_mlp(qf.q2, params["q2"])

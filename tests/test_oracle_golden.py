@@ -124,3 +124,19 @@ def test_torch_port_matches_reference(name):
     want = z["param.q1.w1"]
     got = sub(tr.qf.q1.net[2].weight.detach().numpy(), meta["stride"])
     assert np.max(np.abs(got - want)) <= 1e-7
+
+
+@pytest.mark.parametrize("name", ["g9_dropout_S39A28_gauss", "g9_dropout_S17A6_det"])
+def test_dropout_step_with_injected_masks_matches_reference(name):
+    """Actor dropout: the reference ran with the same keep-masks injected into nn.Dropout."""
+    z, meta = load_golden(name)
+    params, batch, hyper = single_step_inputs(meta)
+    p = meta["dropout"]
+    k0, k1 = synth.synth_dropout_keep(meta["B"], p, seed=meta["seed"])
+    masks = (k0.astype(np.float32) / np.float32(1.0 - p), k1.astype(np.float32) / np.float32(1.0 - p))
+    newp, newo, info = O.iql_step(params, O.new_opt_state(params), batch, hyper, meta["lrs"], actor_masks=masks)
+    info2 = {k: v for k, v in info.items() if k not in ("next_v", "target_q", "adv")}
+    check_step_against_golden(z, meta, info2, newp, newo, grad_rtol=3e-5, param_atol=2e-6, loss_rtol=1e-5,
+                              target_atol=1e-7)
+    bits = synth.pack_keep_bits(k0)
+    assert bits.shape == (meta["B"], 8) and ((bits[3, 1] >> 5) & 1) == int(k0[3, 37])

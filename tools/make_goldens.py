@@ -85,11 +85,12 @@ NET_KEYS = {  # our tensor names -> reference state_dict keys
 }
 
 
-def build_trainer(ref, S, A, params, gaussian, hyper, lrs, max_steps):
+def build_trainer(ref, S, A, params, gaussian, hyper, lrs, max_steps, dropout=0.0):
     qf = ref.TwinQ(S, A)
     vf = ref.ValueFunction(S)
-    actor = (ref.GaussianPolicy if gaussian else ref.DeterministicPolicy)(S, A, 1.0)
+    actor = (ref.GaussianPolicy if gaussian else ref.DeterministicPolicy)(S, A, 1.0, dropout=dropout)
     mods = {"vf": vf, "q1": qf, "q2": qf, "pi": actor}
+    NET_KEYS["pi"] = _pi_keys(actor)
     with torch.no_grad():
         for net, keys in NET_KEYS.items():
             sd = dict(mods[net].named_parameters())
@@ -111,9 +112,21 @@ def build_trainer(ref, S, A, params, gaussian, hyper, lrs, max_steps):
     return tr
 
 
+def _pi_keys(actor):
+    """state_dict keys of the actor's three Linear layers (net.net.{0,2,4} or {0,3,6} with dropout)."""
+    idx = [i for i, m in enumerate(actor.net.net) if isinstance(m, torch.nn.Linear)]
+    k = {}
+    for j, name in enumerate(("0", "1", "2")):
+        k["w" + name] = f"net.net.{idx[j]}.weight"
+        k["b" + name] = f"net.net.{idx[j]}.bias"
+    k["log_std"] = "log_std"
+    return k
+
+
 def grab(tr, stride, gaussian):
     """Current params / grads / Adam moments / target as sub-sampled numpy."""
     out = {}
+    NET_KEYS["pi"] = _pi_keys(tr.actor)
     mods = {"vf": (tr.vf, tr.v_optimizer), "q1": (tr.qf, tr.q_optimizer), "q2": (tr.qf, tr.q_optimizer),
             "pi": (tr.actor, tr.actor_optimizer)}
     for net, keys in NET_KEYS.items():
@@ -189,6 +202,45 @@ def single_step_case(ref, name, S, A, gaussian, beta, iql_tau, B, seed, stride, 
     out["lr_after"] = np.array([tr.actor_optimizer.param_groups[0]["lr"]], dtype=np.float64)
     meta = {"kind": "single_step", "S": S, "A": A, "gaussian": gaussian, "B": B, "seed": seed,
             "stride": stride, "hyper": hyper, "lrs": lrs, "max_steps": 1000, "edge": edge}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez(os.path.join(outdir, name + ".npz"), **out)
+    print(f"{name}: losses={out['losses']}")
+
+
+def dropout_case(ref, name, S, A, gaussian, pdrop, B, seed, stride, outdir):
+    """Single step with actor dropout.  torch's dropout RNG stream cannot be matched by another
+    implementation, so nn.Dropout.forward is replaced (for this call only) by a multiplication with
+    keep-masks drawn from synth.synth_dropout_keep — the reference's MLP / loss / optimiser code runs
+    unmodified, only the random mask is injected."""
+    hyper = {"iql_tau": 0.8, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    params = synth.synth_params(S, A, seed=seed, gaussian=gaussian)
+    data = synth.synth_transitions(B, S, A, seed=1000 + seed)
+    tr = build_trainer(ref, S, A, params, gaussian, hyper, lrs, max_steps=1000, dropout=pdrop)
+    n_drop = sum(isinstance(m, torch.nn.Dropout) for m in tr.actor.modules())
+    assert n_drop == 2, n_drop
+    k0, k1 = synth.synth_dropout_keep(B, pdrop, seed=seed)
+    queue = [torch.from_numpy(k0.astype(np.float32) / np.float32(1.0 - pdrop)),
+             torch.from_numpy(k1.astype(np.float32) / np.float32(1.0 - pdrop))]
+    orig = torch.nn.Dropout.forward
+
+    def injected(self, x):
+        assert self.training and abs(self.p - pdrop) < 1e-12
+        return x * queue.pop(0)
+
+    torch.nn.Dropout.forward = injected
+    try:
+        batch = to_batch(data)
+        log = tr.train(batch)
+    finally:
+        torch.nn.Dropout.forward = orig
+    assert not queue
+    out = grab(tr, stride, gaussian)
+    out["losses"] = np.array([log["value_loss"], log["q_loss"], log["actor_loss"]], dtype=np.float64)
+    out["lr_after"] = np.array([tr.actor_optimizer.param_groups[0]["lr"]], dtype=np.float64)
+    meta = {"kind": "single_step_dropout", "S": S, "A": A, "gaussian": gaussian, "B": B, "seed": seed,
+            "stride": stride, "hyper": hyper, "lrs": lrs, "max_steps": 1000, "edge": False, "dropout": pdrop,
+            "actor_state_keys": list(tr.actor.state_dict().keys())}
     out["meta"] = np.array(json.dumps(meta))
     np.savez(os.path.join(outdir, name + ".npz"), **out)
     print(f"{name}: losses={out['losses']}")
@@ -352,6 +404,8 @@ def main():
     single_step_case(ref, "g7_edge_det", 17, 6, False, 10.0, 0.9, 256, 51, 13, args.out, edge=True)
     single_step_case(ref, "g1_ragged_B100", 17, 6, True, 3.0, 0.7, 100, 52, 13, args.out)
     single_step_case(ref, "g8_dp_B2048", 17, 6, True, 3.0, 0.7, 2048, 60, 13, args.out)
+    dropout_case(ref, "g9_dropout_S39A28_gauss", 39, 28, True, 0.1, 256, 80, 13, args.out)
+    dropout_case(ref, "g9_dropout_S17A6_det", 17, 6, False, 0.25, 256, 81, 13, args.out)
     freerun_case(ref, "g2_freerun_S17A6", 17, 6, True, 10, 256, 4096, 70, 13, args.out)
     freerun_case(ref, "g2_freerun_S29A8_det", 29, 8, False, 10, 256, 4096, 71, 13, args.out)
     gather_case(ref, args.out)
