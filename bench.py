@@ -68,21 +68,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        ge.build()
     import torch.distributed as dist
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev          # (rehearsals put several ranks on one GPU; the driver gives one GPU per rank)
+    backend = os.environ.get("IQLHIP_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only for rehearsals
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    # one rank compiles (a no-op when the prebuilt library is current); the others wait before loading it
+    if rank == 0:
+        ge.build()
+    if world > 1:
         dist.barrier()
     ge._paths()
     import iql
     import synth
 
     S, A, B = args.state_dim, args.action_dim, args.batch
-    dev = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{dev_index}"
+    torch.cuda.set_device(dev_index)
 
     # ---- synthetic HBM-resident buffer + nets (seed 0)
     data = synth.synth_transitions(args.rows, S, A, seed=0)
@@ -103,7 +111,7 @@ def main():
     if force_dp and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29731")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
         tr._dp_world, tr._dp_group = 2, None      # take the split path; the collective runs over 1 rank
         tr._dp_world_scale = 1
     if world > 1:
