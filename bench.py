@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--state-dim", type=int, default=17)
     ap.add_argument("--action-dim", type=int, default=6)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
+                    help="f32 = the parity path (headline); bf16 = bf16 operands / fp32 accumulate in the 256-deep products")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -107,6 +109,8 @@ def main():
         q_network=qf, q_optimizer=torch.optim.Adam(qf.parameters(), lr=3e-4),
         v_network=vf, v_optimizer=torch.optim.Adam(vf.parameters(), lr=3e-4),
         iql_tau=0.7, beta=3.0, max_steps=1_000_000, discount=0.99, tau=0.005, device=dev)
+    if args.precision == "bf16":
+        tr.set_precision("bf16")
     force_dp = os.environ.get("IQLHIP_BENCH_FORCE_DP") == "1"   # diagnostic: 1-rank process group, DP code path
     if force_dp and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -190,7 +194,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.precision,
         "data": "synthetic",
         "config": {"workload": f"IQL step on synthetic buffer (obs={S}, act={A}, {args.rows} rows), batch={B} per GPU",
                    "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",

@@ -57,6 +57,7 @@ struct iqlhip_ctx {
   float drop_p = 0.f;
   unsigned long long drop_seed = 0, drop_step = 0;
   bool drop_inject = false;           // tests: masks were written by iqlhip_debug_write_masks, do not regenerate
+  int precision = 0;                  // 0: fp32 MFMA everywhere; 1: bf16 operands for the 256-deep products
   float* loss_ring = nullptr;         // [ring_cap][4]
   int ring_cap = 0;
   long long* idx_chunk = nullptr;     // [K_max * max_batch]
@@ -190,8 +191,10 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 33 + 4 +
                                 RT_ROWS * 132) * sizeof(float);
   c->lds_bwd = std::max(lds_a, lds_b);
-  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd));
-  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
   *out = c;
   return IQLHIP_OK;
 }
@@ -222,6 +225,14 @@ extern "C" int iqlhip_set_hyper(iqlhip_ctx* c, const iqlhip_hyper* h) {
   if (!c || !h) return fail(IQLHIP_EINVAL, "NULL argument");
   c->hyper = *h;
   drop_graph(c);
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_set_precision(iqlhip_ctx* c, int mode) {
+  if (!c) return fail(IQLHIP_EINVAL, "NULL ctx");
+  if (mode != 0 && mode != 1) return fail(IQLHIP_EINVAL, "precision mode must be 0 (f32) or 1 (bf16 operands)");
+  if (mode != c->precision) drop_graph(c);
+  c->precision = mode;
   return IQLHIP_OK;
 }
 
@@ -377,13 +388,16 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
 
 static void launch_fwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
-  hipLaunchKernelGGL(iql_fwd_kernel, dim3(8 * n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
+  if (c->precision == 1) hipLaunchKernelGGL(iql_fwd_kernel<true>, dim3(8 * n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
+  else hipLaunchKernelGGL(iql_fwd_kernel<false>, dim3(8 * n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
 }
 static void launch_bwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   const int n_chunk = (p.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
   const int per_net = 32 * n_chunk + 4 * n_rt;
-  hipLaunchKernelGGL(iql_bwd_kernel, dim3(8 * ((per_net + 1) / 2)), dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+  const dim3 grid(8 * ((per_net + 1) / 2));
+  if (c->precision == 1) hipLaunchKernelGGL(iql_bwd_kernel<true>, grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+  else hipLaunchKernelGGL(iql_bwd_kernel<false>, grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
 }
 static unsigned drop_thresh(float p) {
   const double t = (double)p * 4294967296.0;

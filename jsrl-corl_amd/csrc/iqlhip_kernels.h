@@ -36,6 +36,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// bf16-operand variant of the three 256-deep products (layer 1 forward, dW1, dH0): fp32 accumulate, fp32
+// master weights / activations in memory; operands are rounded to bf16 in registers (v_cvt_pk_bf16_f32) and
+// eight fp32 MFMAs (8 x 4 k) collapse into one v_mfma_f32_16x16x32_bf16 (32 k).  The operand lane map of the
+// bf16 instruction is "8 k per lane"; since both operands are built from the same (lane, element) -> k
+// assignment, the loads are exactly those of the fp32 path.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ bf16x8 pack8(const f32x4 lo, const f32x4 hi) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = (__bf16)lo[i]; r[4 + i] = (__bf16)hi[i]; }
+  return r;
+}
+__device__ __forceinline__ bf16x8 pack8s(const float (&v)[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
+  return r;
+}
+
 struct DevScratch {
   float* h0;        // [4][max_batch][256]  post-ReLU layer-0 activations of V(s),Q1,Q2,pi
   float* h1;        // [4][max_batch][256]
@@ -118,6 +138,7 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
 // Forward: block = (instance, row tile of 32 rows, column slice ns of 64 hidden-1 units).
 // grid = 8 * n_rt * NSPLIT; blockIdx & 7 = instance (7 = idle) so that the
 // blocks of one instance share an XCD and hence one L2 copy of its weights.
+template <bool BF16>
 __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   const int bid = blockIdx.x;
   const int inst = bid & 7;
@@ -362,14 +383,27 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   // ---- layer 1: this wave computes H1[32][16 units]; A = W1 fragments (m = unit), B = H0 (n = row)
   {
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    if (BF16) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const f32x4 a0 = *(const f32x4*)(H0s + l15 * H0_LD + 16 * ks + 4 * g);
-      const f32x4 a1 = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 16 * ks + 4 * g);
+      for (int j = 0; j < 8; ++j) {     // one bf16 MFMA per 32 k: lane (g) supplies k = 32j + {4g..4g+3, 16+4g..16+4g+3}
+        const bf16x8 a = pack8(bw[2 * j], bw[2 * j + 1]);
+        const bf16x8 b0 = pack8(*(const f32x4*)(H0s + l15 * H0_LD + 32 * j + 4 * g),
+                                *(const f32x4*)(H0s + l15 * H0_LD + 32 * j + 16 + 4 * g));
+        const bf16x8 b1 = pack8(*(const f32x4*)(H0s + (16 + l15) * H0_LD + 32 * j + 4 * g),
+                                *(const f32x4*)(H0s + (16 + l15) * H0_LD + 32 * j + 16 + 4 * g));
+        acc0 = MFMA_BF16(a, b0, acc0);
+        acc1 = MFMA_BF16(a, b1, acc1);
+      }
+    } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc0 = MFMA16(bw[ks][t], a0[t], acc0);
-        acc1 = MFMA16(bw[ks][t], a1[t], acc1);
+      for (int ks = 0; ks < 16; ++ks) {
+        const f32x4 a0 = *(const f32x4*)(H0s + l15 * H0_LD + 16 * ks + 4 * g);
+        const f32x4 a1 = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 16 * ks + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc0 = MFMA16(bw[ks][t], a0[t], acc0);
+          acc1 = MFMA16(bw[ks][t], a1[t], acc1);
+        }
       }
     }
     f32x4 h0, h1;
@@ -571,6 +605,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /*>=4 floats*
 // Backward.  blockIdx & 7 = x: net = x & 3, half = x >> 2 (two XCD groups per net).
 // Within a net, local id < 32*n_chunk  -> (a) block: chunk c, j-tile jt (32 rows of W1), i-tile it (64 cols)
 //               otherwise              -> (b) block: row tile rt (32 rows), i-slice is (64 cols)
+template <bool BF16>
 __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk, int n_rt) {
   const int bid = blockIdx.x;
   const int x = bid & 7;
@@ -746,12 +781,37 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (BF16) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+      for (int q = 0; q < 2; ++q) {       // rows (k) 8q..8q+7 of this lane's 16
+        bf16x8 A[2], Bv[4];
 #pragma unroll
-      for (int ta = 0; ta < 2; ++ta)
+        for (int ta = 0; ta < 2; ++ta) {
+          float t8[8];
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = MFMA16(av[ks][ta], bb[ks][tb], acc[ta][tb]);
+          for (int e = 0; e < 8; ++e) t8[e] = av[8 * q + e][ta];
+          A[ta] = pack8s(t8);
+        }
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          float t8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t8[e] = bb[8 * q + e][tb];
+          Bv[tb] = pack8s(t8);
+        }
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = MFMA_BF16(A[ta], Bv[tb], acc[ta][tb]);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = MFMA16(av[ks][ta], bb[ks][tb], acc[ta][tb]);
+      }
     }
     f32x4 acc2[2][2];   // dW2 tiles [dt][tb] (MFMA path, D > 1, extras blocks only)
 #pragma unroll
@@ -952,15 +1012,38 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (BF16) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int kk = 64 * wave + 4 * ks + g;
-        const float a0 = dH1s[l15 * H0_LD + kk];
-        const float a1 = dH1s[(16 + l15) * H0_LD + kk];
+        for (int q = 0; q < 2; ++q) {     // k = j index: 64w + 4(8q+e) + g, e = 0..7
+          float t0[8], t1[8];
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
-          acc[0][tb] = MFMA16(a0, bw[ks][tb], acc[0][tb]);
-          acc[1][tb] = MFMA16(a1, bw[ks][tb], acc[1][tb]);
+          for (int e = 0; e < 8; ++e) {
+            const int kk = 64 * wave + 4 * (8 * q + e) + g;
+            t0[e] = dH1s[l15 * H0_LD + kk];
+            t1[e] = dH1s[(16 + l15) * H0_LD + kk];
+          }
+          const bf16x8 A0 = pack8s(t0), A1 = pack8s(t1);
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) {
+            float t8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t8[e] = bw[8 * q + e][tb];
+            const bf16x8 Bv = pack8s(t8);
+            acc[0][tb] = MFMA_BF16(A0, Bv, acc[0][tb]);
+            acc[1][tb] = MFMA_BF16(A1, Bv, acc[1][tb]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const int kk = 64 * wave + 4 * ks + g;
+          const float a0 = dH1s[l15 * H0_LD + kk];
+          const float a1 = dH1s[(16 + l15) * H0_LD + kk];
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) {
+            acc[0][tb] = MFMA16(a0, bw[ks][tb], acc[0][tb]);
+            acc[1][tb] = MFMA16(a1, bw[ks][tb], acc[1][tb]);
+          }
         }
       }
       float* myred = red + wave * 32 * T64_LD;

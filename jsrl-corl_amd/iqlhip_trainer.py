@@ -155,6 +155,8 @@ class ImplicitQLearning:
         self._hyper_sent = self._hyper_tuple()
         self._dropout_sent = 0.0
         self._max_batch = max_batch
+        if getattr(self, "_precision", "f32") == "bf16":     # survives a re-attach for a larger batch
+            hb.check(hb.lib().iqlhip_set_precision(self._ctx, 1))
         hb.check(hb.lib().iqlhip_bind(self._ctx, self._params_arena.data_ptr(), self._target_arena.data_ptr(),
                                       self._m_arena.data_ptr(), self._v_arena.data_ptr()))
 
@@ -604,6 +606,15 @@ class ImplicitQLearning:
         out = C.c_float(0)
         hb.check(hb.lib().iqlhip_debug_time_kernel(self._ctx, C.byref(b), which, repeat, C.byref(out), self._stream()))
         return float(out.value)
+
+    def set_precision(self, mode: str) -> None:
+        """"f32" (default, the parity path) or "bf16": bf16 operands / fp32 accumulate for the 256-deep
+        products (BASELINE config 5's MFMA bf16 path).  Not part of the reference's surface."""
+        self._require_gpu()
+        if mode not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self._precision = mode
+        hb.check(hb.lib().iqlhip_set_precision(self._ctx, 1 if mode == "bf16" else 0))
 
     def inject_dropout_masks(self, keep0: np.ndarray, keep1: np.ndarray) -> None:
         """Tests: use these keep-masks (bool [rows,256] per layer) for the following steps instead of device draws."""

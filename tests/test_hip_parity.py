@@ -335,3 +335,56 @@ def test_dropout_in_graph_steps_is_seeded_and_varies_per_step():
             assert np.array_equal(runs[0][1][n][k], runs[1][1][n][k])
     assert np.allclose(runs[0][0][0, :2], l0[0, :2], rtol=0, atol=0)      # step 0: identical V and Q losses
     assert not np.allclose(runs[0][0][:, 2], l0[:, 2])                   # actor loss differs (masks applied)
+
+
+@pytest.mark.parametrize("name", ["g1_S17A6_gauss_b3", "g1_S39A28_gauss_b10", "g1_S29A8_det_b10"])
+def test_bf16_operand_mode_tracks_fp32_reference(name):
+    """BASELINE config 5's "MFMA bf16 path": bf16 operands / fp32 accumulate in the three 256-deep products.
+    Tolerance: losses rel <= 2e-2 single-step vs the fp32 reference fixture; gradients within
+    1e-1 in relative L2 norm per tensor (bf16 operands carry 8 significant bits; observed worst 5.1e-2)."""
+    build, _, _, _, to_tb, unflat = _hip()
+    z, meta = load_golden(name)
+    params, batch, hyper = single_step_inputs(meta)
+    tr = build(params, meta["S"], meta["A"], meta["gaussian"], hyper, meta["lrs"], meta["max_steps"])
+    tr.set_precision("bf16")
+    tb = to_tb(batch)
+    grads, lw = unflat(tr, tr.flat_gradient(tb))
+    assert_losses(lw, z["losses"], 2e-2)
+    from oracle import iql_oracle as O
+    info = O.iql_losses_and_grads(params, batch, hyper)
+    worst = 0.0
+    for n, t in grads.items():
+        for k, g in t.items():
+            want = info["grads"][n][k]
+            rel = float(np.linalg.norm(g - want) / max(np.linalg.norm(want), 1e-30))
+            worst = max(worst, rel)
+            assert rel <= 1e-1, (n, k, rel)
+    assert worst > 1e-5          # the mode really is active (fp32 would sit at ~1e-7)
+    log = tr.train(tb)
+    assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"], 2e-2)
+    tr.set_precision("f32")
+    log2 = tr.train(tb)
+    assert all(np.isfinite(v) for v in log2.values())
+
+
+def test_bf16_large_batch_config5_shape():
+    """obs=39, act=28, 1024 rows per GPU (config 5 at 8 GPUs), Gaussian policy with dropout 0.1: runs, finite,
+    and the bf16 losses track the fp32 losses of the same step."""
+    build, _, _, _, to_tb, _ = _hip()
+    S, A, B = 39, 28, 1024
+    params = synth.synth_params(S, A, seed=61)
+    hyper = {"iql_tau": 0.8, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    d = synth.synth_transitions(B, S, A, seed=62)
+    batch = {"s": d["observations"], "a": d["actions"], "r": d["rewards"], "ns": d["next_observations"],
+             "d": d["terminals"]}
+    k0, k1 = synth.synth_dropout_keep(B, 0.1, seed=63)
+    a = build(params, S, A, True, hyper, lrs, 1000, dropout=0.1)
+    a.inject_dropout_masks(k0, k1)
+    la = a.train(to_tb(batch))
+    b = build(params, S, A, True, hyper, lrs, 1000, dropout=0.1)
+    b.set_precision("bf16")
+    b.inject_dropout_masks(k0, k1)
+    lb = b.train(to_tb(batch))
+    for k in la:
+        assert np.isfinite(lb[k]) and abs(lb[k] - la[k]) <= 2e-2 * abs(la[k]), (k, la[k], lb[k])

@@ -23,4 +23,7 @@ for (S, A, B) in ((17, 6, 256), (29, 8, 256), (39, 28, 256), (17, 6, 2048)):
     tr.train(tb)
     t = [tr.time_kernel(tb, w, 300) for w in (0, 1, 2, 3)]
     print(f"S={S} A={A} B={B}: fwd {t[0]:.2f} us  bwd {t[1]:.2f} us  update {t[2]:.2f} us  all3 {t[3]:.2f} us/step", flush=True)
+    tr.set_precision("bf16")
+    t = [tr.time_kernel(tb, w, 300) for w in (0, 1, 2, 3)]
+    print(f"   bf16 operands     : fwd {t[0]:.2f} us  bwd {t[1]:.2f} us  update {t[2]:.2f} us  all3 {t[3]:.2f} us/step", flush=True)
     del tr
