@@ -184,12 +184,12 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   const int kq = dims->state_dim + dims->action_dim;
   const int ks_ = dims->state_dim;   // V / pi layer-0 width; Q nets use kq
   const int w0_lds_k = (kq <= W0_LDS_MAX_K) ? kq : ((ks_ <= W0_LDS_MAX_K) ? ks_ : 0);
-  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * 132 + IQLHIP_MAX_ACTION * 65 + 512 + 16 +
+  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * XR_LD_MAX + IQLHIP_MAX_ACTION * 65 + 512 + 16 +
                         HID * w0_lds_k) * sizeof(float);
   const int dyld = ((A + 15) & ~15) + 1;
   const size_t lds_a = (size_t)(4 * 32 * T64_LD + 2 * CHUNK_ROWS * dyld + 32 * 32 + 64) * sizeof(float);
   const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 33 + 4 +
-                                RT_ROWS * 132) * sizeof(float);
+                                RT_ROWS * XR_LD_MAX) * sizeof(float);
   c->lds_bwd = std::max(lds_a, lds_b);
   HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd));
   HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));

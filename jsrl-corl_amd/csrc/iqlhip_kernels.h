@@ -126,7 +126,32 @@ struct StepParams {
 #define PIN_P(x) asm volatile("" ::"s"((unsigned long long)(uintptr_t)(x)))
 
 // ---------------------------------------------------------------------------
-#define XR_MAX_F4 5          // float4 per thread to cover a 32-row packed tile: ceil(32*132/4/256)
+// A 32-row tile of packed rows is staged whole (flat float4 copy).  The packed stride 2S+A+2 (padded to 4)
+// reaches 260 floats at the dimension limits, i.e. up to 9 float4 per thread; the common dims need 2-4, so the
+// copy is instantiated for 3 / 5 / 9 (straight-line loads each: a load under a run-time trip count would be
+// waited for individually).
+#define XR_MAX_F4 9
+#define XR_LD_MAX 260
+template <int N>
+__device__ __forceinline__ void xr_issue(f32x4 (&xr)[XR_MAX_F4], const float* xb, int first_f4, int n_x, int x_last) {
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const int f = min(first_f4 + min((int)threadIdx.x + 256 * q, n_x - 1), x_last);
+    xr[q] = *(const f32x4*)(xb + 4 * f);
+  }
+}
+__device__ __forceinline__ void xr_load(f32x4 (&xr)[XR_MAX_F4], const float* xb, int first_f4, int n_x, int x_last) {
+  if (n_x <= 3 * 256) xr_issue<3>(xr, xb, first_f4, n_x, x_last);
+  else if (n_x <= 5 * 256) xr_issue<5>(xr, xb, first_f4, n_x, x_last);
+  else xr_issue<9>(xr, xb, first_f4, n_x, x_last);
+}
+__device__ __forceinline__ void xr_store(const f32x4 (&xr)[XR_MAX_F4], float* Xr, int n_x) {
+#pragma unroll
+  for (int q = 0; q < XR_MAX_F4; ++q) {
+    const int f = (int)threadIdx.x + 256 * q;
+    if (f < n_x) *(f32x4*)(Xr + 4 * f) = xr[q];
+  }
+}
 
 __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_base) {
   // 64 lanes x 16 B: global (per-lane address) -> LDS (wave-uniform base + lane*16), no VGPR staging
@@ -173,7 +198,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   float* H0s = smem;                         // [32][H0_LD]
   float* H1s = H0s + RT_ROWS * H0_LD;        // [32][T64_LD]
   float* Xr = H1s + RT_ROWS * T64_LD;        // [32][ld]  packed rows of this tile
-  float* W2s = Xr + RT_ROWS * 132;           // [D][64] head weights of this column slice, then b2[D]
+  float* W2s = Xr + RT_ROWS * XR_LD_MAX;     // [D][64] head weights of this column slice, then b2[D]
   unsigned* Mk = (unsigned*)(W2s + IQLHIP_MAX_ACTION * 65);   // [2][32][8] dropout keep-bits of the tile
   float* W0s = W2s + IQLHIP_MAX_ACTION * 65 + 512;   // [256*k0] flat copy of layer-0 weights (when w0_lds); 16-B aligned
   // (no integer casts on LDS pointers: they would demote every access to a flat load, and a flat load
@@ -187,11 +212,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   const int n_x = RT_ROWS * ld / 4;
   const int x_last = B * ld / 4 - 1;
   f32x4 xr[XR_MAX_F4];
-#pragma unroll
-  for (int q = 0; q < XR_MAX_F4; ++q) {
-    const int f = min(row0 * ld / 4 + min(tid + 256 * q, n_x - 1), x_last);
-    xr[q] = *(const f32x4*)(xb + 4 * f);
-  }
+  xr_load(xr, xb, row0 * ld / 4, n_x, x_last);
   // (b) head weights of this slice + b2, biases
   f32x4 w2pre[2];
 #pragma unroll
@@ -229,11 +250,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + n1 * HID + 16 * ks + 4 * g);
 
-#pragma unroll
-  for (int q = 0; q < XR_MAX_F4; ++q) {
-    const int f = tid + 256 * q;
-    if (f < n_x) *(f32x4*)(Xr + 4 * f) = xr[q];
-  }
+  xr_store(xr, Xr, n_x);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int e = tid + 256 * q;
@@ -955,11 +972,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     const int n_x = RT_ROWS * ld / 4;
     const int x_last = B * ld / 4 - 1;
     f32x4 xr[XR_MAX_F4];
-#pragma unroll
-    for (int q = 0; q < XR_MAX_F4; ++q) {
-      const int f = min(row0 * ld / 4 + min(tid + 256 * q, n_x - 1), x_last);
-      xr[q] = *(const f32x4*)(p.xb + 4 * f);
-    }
+    xr_load(xr, p.xb, row0 * ld / 4, n_x, x_last);
 
     const PiConst pc = pi_consts(p, net);
     if (tid < RT_ROWS) {
@@ -1057,11 +1070,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         }
     }
     // park the packed rows for the dW0 product
-#pragma unroll
-    for (int q = 0; q < XR_MAX_F4; ++q) {
-      const int f = tid + 256 * q;
-      if (f < n_x) *(f32x4*)(Xr + 4 * f) = xr[q];
-    }
+    xr_store(xr, Xr, n_x);
     __syncthreads();
     STAMP(p, 7);
 #pragma unroll

@@ -356,6 +356,11 @@ def test_bf16_operand_mode_tracks_fp32_reference(name):
     for n, t in grads.items():
         for k, g in t.items():
             want = info["grads"][n][k]
+            if want.size <= 32:
+                # head-bias / log_std gradients are means of signed residuals (heavy cancellation): their own
+                # norm is no yardstick — bound the absolute error against the residual scale (O(1)) instead
+                assert np.max(np.abs(g - want)) <= 2e-2 * max(1.0, float(np.max(np.abs(want)))), (n, k)
+                continue
             rel = float(np.linalg.norm(g - want) / max(np.linalg.norm(want), 1e-30))
             worst = max(worst, rel)
             assert rel <= 1e-1, (n, k, rel)
@@ -388,3 +393,43 @@ def test_bf16_large_batch_config5_shape():
     lb = b.train(to_tb(batch))
     for k in la:
         assert np.isfinite(lb[k]) and abs(lb[k] - la[k]) <= 2e-2 * abs(la[k]), (k, la[k], lb[k])
+
+
+@pytest.mark.parametrize("S,A,B,gaussian", [
+    (100, 28, 64, True),     # k_in = 128 (limit): layer-0 weights streamed from global, 8 k-tiles in dW0
+    (96, 32, 40, False),     # action_dim = 32 (limit): two 16-wide head tiles, four pi chunks
+    (2, 1, 256, True),       # smallest dims
+    (17, 6, 1, True),        # single row
+    (17, 6, 257, True),      # one row past a 256-row chunk
+    (50, 10, 300, True),     # k_in = 60 (V: 50): LDS-staged W0 through the generic k loop
+])
+def test_edge_shapes_match_oracle(S, A, B, gaussian):
+    from oracle import iql_oracle as O
+    build, _, _, read_params, to_tb, unflat = _hip()
+    params = synth.synth_params(S, A, seed=7 * S + A, gaussian=gaussian)
+    d = synth.synth_transitions(B, S, A, seed=S + A + B)
+    batch = {"s": d["observations"], "a": d["actions"], "r": d["rewards"], "ns": d["next_observations"],
+             "d": d["terminals"]}
+    hyper = {"iql_tau": 0.9, "beta": 10.0, "discount": 0.99, "tau": 0.005, "deterministic": not gaussian}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    tr = build(params, S, A, gaussian, hyper, lrs, 1000)
+    newp, newo, info = O.iql_step(params, O.new_opt_state(params), batch, hyper, lrs)
+    grads, lw = unflat(tr, tr.flat_gradient(to_tb(batch)))
+    assert_losses(lw, [info["value_loss"], info["q_loss"], info["actor_loss"]], 2e-5)
+    for n, t in grads.items():
+        for k, g in t.items():
+            want = info["grads"][n][k]
+            assert np.max(np.abs(g - want)) <= 5e-5 * max(np.max(np.abs(want)), 1e-30), (n, k)
+    log = tr.train(to_tb(batch))
+    assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]],
+                  [info["value_loss"], info["q_loss"], info["actor_loss"]], 2e-5)
+    got = read_params(tr)
+    for n, t in got.items():
+        for k, p in t.items():
+            diff = np.abs(p - newp[n][k])
+            if n in ("qt1", "qt2"):
+                assert diff.max() <= 1e-6, (n, k)
+            else:   # Adam amplifies rounding of near-eps gradients: allow it exactly there (see helpers.py)
+                gref = np.abs(info["grads"][n][k])
+                tol = 2e-6 + 3e-4 * np.minimum(1.0, 1e-8 * (2e-6 * max(gref.max(), 1e-30)) / (gref + 1e-8) ** 2)
+                assert np.all(diff <= tol), (n, k, float(diff.max()))
