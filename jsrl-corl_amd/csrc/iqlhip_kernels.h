@@ -132,18 +132,22 @@ struct StepParams {
 // waited for individually).
 #define XR_MAX_F4 9
 #define XR_LD_MAX 260
-template <int N>
+template <int Q0, int Q1>
 __device__ __forceinline__ void xr_issue(f32x4 (&xr)[XR_MAX_F4], const float* xb, int first_f4, int n_x, int x_last) {
 #pragma unroll
-  for (int q = 0; q < N; ++q) {
+  for (int q = Q0; q < Q1; ++q) {
     const int f = min(first_f4 + min((int)threadIdx.x + 256 * q, n_x - 1), x_last);
     xr[q] = *(const f32x4*)(xb + 4 * f);
   }
 }
 __device__ __forceinline__ void xr_load(f32x4 (&xr)[XR_MAX_F4], const float* xb, int first_f4, int n_x, int x_last) {
-  if (n_x <= 3 * 256) xr_issue<3>(xr, xb, first_f4, n_x, x_last);
-  else if (n_x <= 5 * 256) xr_issue<5>(xr, xb, first_f4, n_x, x_last);
-  else xr_issue<9>(xr, xb, first_f4, n_x, x_last);
+#pragma unroll
+  for (int q = 0; q < XR_MAX_F4; ++q) xr[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  xr_issue<0, 3>(xr, xb, first_f4, n_x, x_last);
+  if (n_x > 3 * 256) {
+    xr_issue<3, 5>(xr, xb, first_f4, n_x, x_last);
+    if (n_x > 5 * 256) xr_issue<5, 9>(xr, xb, first_f4, n_x, x_last);
+  }
 }
 __device__ __forceinline__ void xr_store(const f32x4 (&xr)[XR_MAX_F4], float* Xr, int n_x) {
 #pragma unroll
@@ -457,14 +461,18 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       }
     }
     // ---- head partial sums over this block's 64 hidden-1 units (slice 0 also adds the bias)
+    // thread (row rl, sub): units 4 sub..4 sub+3 and 32+4 sub..; its H1 values are read once, not once per dim
+    const f32x4 ha = *(const f32x4*)(H1s + rl * T64_LD + 4 * sub);
+    const f32x4 hb = *(const f32x4*)(H1s + rl * T64_LD + 32 + 4 * sub);
     for (int dd = 0; dd < D; ++dd) {
       const float* w2r = W2s + dd * 64;
+      const f32x4 wa = *(const f32x4*)(w2r + 4 * sub);
+      const f32x4 wb = *(const f32x4*)(w2r + 32 + 4 * sub);
       float acc = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = sub + 8 * j;
-        acc = fmaf(H1s[rl * T64_LD + c], w2r[c], acc);
-      }
+      for (int e = 0; e < 4; ++e) acc = fmaf(ha[e], wa[e], acc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = fmaf(hb[e], wb[e], acc);
       acc += __shfl_xor(acc, 1);
       acc += __shfl_xor(acc, 2);
       acc += __shfl_xor(acc, 4);
@@ -499,7 +507,7 @@ __device__ __forceinline__ void row_issue(const StepParams& p, int net, int row,
   const float* xr = p.xb + row * p.ld + 2 * p.S + p.A;
   in.r = xr[0];
   in.d = xr[1];
-  if (net == IQLHIP_NET_PI) {
+  if (net == IQLHIP_NET_PI) {      // (callers pass -1 when they load the policy inputs themselves)
     const int A = p.A;
     const float* arow = p.xb + row * p.ld + p.S;
     const f32x4* hp = (const f32x4*)(p.sc.heads + p.sc.max_batch * HEAD_LD + row * A * NSPLIT);
@@ -524,12 +532,17 @@ __device__ __forceinline__ float tanh_via_exp(float x) { return 1.f - 2.f / (exp
 // Per-action-dim constants of the Gaussian policy (clamped log_std, 1/var): lane dd holds dim dd's.
 // Must be called with ALL lanes of the wave active (row_finish reads them with a lane broadcast).
 struct PiConst { float ls, ivar; };
-__device__ __forceinline__ PiConst pi_consts(const StepParams& p, int net) {
+// The raw log_std word is loaded by pi_ls_issue() BEFORE the block's big prefetches: vmcnt retires in issue
+// order, so a load issued after them would make the loss arithmetic wait for all of them.
+__device__ __forceinline__ float pi_ls_issue(const StepParams& p) {
+  const float* src = (p.policy == IQLHIP_POLICY_GAUSSIAN) ? p.log_std : p.xb;      // any valid address when unused
+  return src[min((int)(threadIdx.x & 63), p.A - 1)];
+}
+__device__ __forceinline__ PiConst pi_consts(const StepParams& p, int net, float lsr) {
   PiConst c;
   c.ls = 0.f;
   c.ivar = 1.f;
   if (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) {
-    const float lsr = p.log_std[min((int)(threadIdx.x & 63), p.A - 1)];
     c.ls = fminf(fmaxf(lsr, p.hy.log_std_min), p.hy.log_std_max);
     const float sig = expf(c.ls);
     c.ivar = 1.f / (sig * sig);
@@ -683,6 +696,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // inputs first, then the 96 KiB of activation tiles, which stream in under the dY arithmetic.
     const int prow = cbase + tid;
     RowIn in;
+    const float lsr = pi_ls_issue(p);
     row_issue(p, net, min(prow, B - 1), in);
     float w2pre[4];
 #pragma unroll
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
       float* dlsrow = (designated && net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) ? (dLs + tid * DYLD) : nullptr;
       if (dlsrow) for (int dd = 0; dd < Dp; ++dd) dlsrow[dd] = 0.f;
-      const PiConst pc = pi_consts(p, net);
+      const PiConst pc = pi_consts(p, net, lsr);
       if (row < B) row_finish(p, net, row, in, pc, dyrow, dlsrow, lossA, lossB);
       STAMP(p, 11);
       if (designated) {
@@ -937,7 +951,30 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // ---- issue every global load of the block, first-needed first (vmcnt retires in issue order)
     RowIn in;
     const int prow = min(row0 + (tid & 31), B - 1);
-    row_issue(p, net, prow, in);
+    const float lsr = pi_ls_issue(p);
+    row_issue(p, (net == IQLHIP_NET_PI) ? -1 : net, prow, in);      // (the policy's own inputs: below)
+    // policy: the loss arithmetic of the 32 rows is spread over all 256 threads — thread (row tid>>3,
+    // dims (tid&7) + 8c) — instead of 32 threads walking all dims while 224 wait at the barrier
+    const int prl = tid >> 3, psub = tid & 7;
+    const int prow8 = min(row0 + prl, B - 1);
+    f32x4 ph[3], php[4];
+    float pac[4];
+    if (net == IQLHIP_NET_PI) {
+      const f32x4* hs = (const f32x4*)(p.sc.heads + prow8 * HEAD_LD);
+      ph[0] = hs[1]; ph[1] = hs[2]; ph[2] = hs[3];
+      const float* arow = p.xb + prow8 * p.ld + p.S;
+      const f32x4* hp = (const f32x4*)(p.sc.heads + MB * HEAD_LD + prow8 * p.A * NSPLIT);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        php[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        pac[c] = 0.f;
+        if (c == 0 || 8 * c < p.A) {               // block-uniform: dims >= 8 only for wide action spaces
+          const int dd = min(psub + 8 * c, p.A - 1);
+          php[c] = hp[dd];
+          pac[c] = arow[dd];
+        }
+      }
+    }
     // W2 rows matching this thread's H1 columns (all threads use cols 4*(tid&63)): row 0 for the scalar
     // heads, rows 0..7 for the policy (issued now, ahead of the W1 stream; rows >= 8 are loaded later)
     const int j4 = tid & 63;
@@ -968,14 +1005,33 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       const int row = min(row0 + (f >> 4), B - 1);
       h0v[q] = *(const f32x4*)(H0g + row * HID + i0 + 4 * (f & 15));
     }
-    // the 32 packed rows (needed last, for dW0)
     const int n_x = RT_ROWS * ld / 4;
     const int x_last = B * ld / 4 - 1;
-    f32x4 xr[XR_MAX_F4];
-    xr_load(xr, p.xb, row0 * ld / 4, n_x, x_last);
 
-    const PiConst pc = pi_consts(p, net);
-    if (tid < RT_ROWS) {
+    const PiConst pc = pi_consts(p, net, lsr);
+    if (net == IQLHIP_NET_PI) {
+      const float tq = fminf(sum4(ph[1]), sum4(ph[2]));
+      const float u = tq - sum4(ph[0]);
+      const float w = fminf(expf(p.hy.beta * u), p.hy.exp_adv_max);
+      const bool rvalid = (row0 + prl) < B;
+      const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd = psub + 8 * c;
+        if (dd < Dp) {
+          float dy = 0.f;
+          const int ddc = min(dd, p.A - 1);
+          const float ivar = __shfl(pc.ivar, ddc);        // lane ddc holds dim ddc's constants; whole wave active
+          if (rvalid && dd < p.A) {
+            const float mu = tanh_via_exp(sum4(php[c]));
+            const float diff = pac[c] - mu;
+            const float dmu = gauss ? (-(w * diff) * ivar) * p.inv_batch : (-2.f * w * diff) * p.inv_batch;
+            dy = dmu * (1.f - mu * mu);
+          }
+          dYs[prl * DYLD + dd] = dy;
+        }
+      }
+    } else if (tid < RT_ROWS) {
       const int row = row0 + tid;
       float la, lbv;
       float* dyrow = dYs + tid * DYLD;
@@ -992,6 +1048,15 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       f32x4 s;
       if (D == 1) {
         s = dYs[rl * DYLD] * w2v;
+      } else if (D <= 8) {
+        // dYs is zero-filled up to Dp >= 8 and w2v8[j >= D] repeats row D-1: 8 unconditional LDS reads in one
+        // batch (a per-dim `if` makes each read -> wait -> fma a serial ~160-cycle step)
+        float dy8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dy8[j] = dYs[rl * DYLD + j];
+        s = dy8[0] * w2v8[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += dy8[j] * w2v8[j];
       } else {
         s = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int d0 = 0; d0 < D; d0 += 8) {
@@ -1014,9 +1079,16 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
       *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+      if (q == 0) STAMP(p, 12);
+      if (q == 3) STAMP(p, 13);
+      if (q == 7) STAMP(p, 14);
     }
     __syncthreads();
     STAMP(p, 6);
+    // the 32 packed rows, needed last (dW0): issued only now — the H1 / W2 registers are free again, the loads
+    // queue behind the W1 fragments (so waiting for those does not wait for these) and the MFMA phase hides them
+    f32x4 xr[XR_MAX_F4];
+    xr_load(xr, p.xb, row0 * ld / 4, n_x, x_last);
 
     // dH0 partial over this wave's 64 j's: [32 rows][64 cols]
     {

@@ -73,6 +73,24 @@ def assert_losses(got, want, rtol=1e-5, what=""):
     assert np.all(err <= rtol), f"{what} losses {got} vs {want}: rel err {err}"
 
 
+def assert_params_after_free_run(got, want, n_steps, lr, what=""):
+    """Parameters after n free-running Adam steps against the reference's.
+
+    Two mechanisms legitimately turn a different (equally valid) fp32 summation order into visible differences:
+      * Adam's update lr*m/(sqrt(v)+eps) maps a ~1e-8 gradient perturbation to O(1e-7) for the few elements whose
+        gradient is itself ~eps, and
+      * such a 1e-7 parameter difference can flip the ReLU mask of ONE hidden unit for ONE row on the next batch,
+        which changes that unit's gradient by a row's share and then its whole weight row by O(lr) per step
+        (observed: fixture g2_freerun_S29A8_det, Q2 unit 169 at step 1 — see DESIGN.md "free-run tolerance").
+    So the per-element bound is the hard cap 1.5*n_steps*lr, and the bulk must agree: RMS <= 5e-6 and at most 2 %
+    of the elements (a couple of units' rows) off by more than 2e-6.  Single-step fixtures stay at ~1e-7."""
+    d = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64)).ravel()
+    assert d.max() <= 1.5 * n_steps * lr, (what, "max", d.max())
+    assert np.sqrt(np.mean(d * d)) <= 5e-6, (what, "rms", np.sqrt(np.mean(d * d)))
+    assert np.sum(d > 2e-6) <= max(2, 0.02 * d.size), (what, "outliers", np.mean(d > 2e-6))
+    assert np.median(d) <= 5e-7, (what, "median", np.median(d))
+
+
 def check_step_against_golden(z, meta, info, newp, newo, *, grad_rtol=1e-5, param_atol=2e-6,
                               moment_rtol=1e-5, target_atol=1e-6, loss_rtol=1e-5, check_moments=True):
     """Teacher-forced single-step tolerances of SURVEY.md §8(d).

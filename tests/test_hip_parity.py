@@ -11,7 +11,8 @@ import pytest
 import torch
 
 import synth
-from helpers import (FREERUN_CASES, SINGLE_STEP_CASES, assert_losses, batch_from, check_step_against_golden,
+from helpers import (FREERUN_CASES, SINGLE_STEP_CASES, assert_losses, assert_params_after_free_run, batch_from,
+                     check_step_against_golden,
                      load_golden, single_step_inputs, sub)
 
 pytestmark = pytest.mark.gpu
@@ -63,7 +64,8 @@ def test_free_run_10_steps_matches_reference(name):
     for net, tensors in got.items():
         for t, p in tensors.items():
             want = z[f"param.{net}.{t}"]
-            assert np.max(np.abs(sub(p, meta["stride"]).reshape(want.shape) - want)) <= 2e-5, (net, t)
+            lr = meta["lrs"]["pi" if net == "pi" else ("v" if net == "vf" else "q")]
+            assert_params_after_free_run(sub(p, meta["stride"]).reshape(want.shape), want, meta["n_steps"], lr, (net, t))
 
 
 def test_free_run_through_replay_buffer_and_numpy_rng():

@@ -67,6 +67,16 @@ ids = np.arange(nb)
 local = (ids >> 3) * 2 + ((ids & 7) >> 2)
 a_blocks = bw[local < 32 * n_chunk]
 b_blocks = bw[(local >= 32 * n_chunk) & (local < per_net)]
+LAB_A = [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
+         (4, "reduce + store (+extras)")]
+LAB_B = [(5, "W1 prefetch+gather+dY(32)"), (12, "dH1 q0"), (13, "dH1 q1-3"), (14, "dH1 q4-7"), (6, "dH1 barrier"), (7, "128 MFMA + red write"), (8, "reduce+mask"), (9, "dW0 MFMA + stores")]
+if os.environ.get("PER_NET"):
+    for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
+        isn = (ids & 3) == n
+        report(f"bwd (a) net {nm}", bw[(local < 32 * n_chunk) & isn], LAB_A)
+        report(f"bwd (b) net {nm}", bw[(local >= 32 * n_chunk) & (local < per_net) & isn], LAB_B)
+    for i, nm in enumerate(("V(s)", "Q1", "Q2", "PI", "V(s')", "Qt1", "Qt2")):
+        report(f"fwd inst {nm}", fwd_blocks[(fwd_blocks & 7) == i], [(1, "prefetch+gather"), (2, "layer0"), (3, "H0 save + layer1"), (4, "H1 save + head")])
 report("bwd (a) dW1 tiles", a_blocks, [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
                                         (4, "reduce + store (+extras)")])
 report("bwd (b) dH0/dW0", b_blocks, [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"),
