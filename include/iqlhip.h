@@ -183,6 +183,18 @@ int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t state_dim, int
 /* Device-side index draw used by iqlhip_train_steps, exposed for tests. */
 int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---- policy inference ---------------------------------------------------- */
+/* GaussianPolicy.act (algorithms/finetune/iql.py:371-379), DeterministicPolicy.act (:404-413) and the batched policy
+ * forward of evaluation loops (eval_actor, jsrl_w_iql.py:62-179):
+ *   actions[r] = clamp(max_action * (tanh(MLP_pi(states[r])) + exp(clamp(log_std)) * noise[r]), -max_action, max_action)
+ * noise_dev == NULL gives the mean (eval mode, or the deterministic policy); with a Gaussian policy in training mode
+ * the caller passes standard-normal noise [rows][action_dim] (dist.sample() of iql.py:376).  Dropout is NOT applied
+ * (eval-mode forward).  rows <= max(max_batch, IQLHIP_ACT_ROWS) per call.  Uses the bound parameter arena;
+ * asynchronous on `stream`. */
+#define IQLHIP_ACT_ROWS 4096
+int iqlhip_actor_forward(iqlhip_ctx* ctx, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
+                         int64_t ld_noise, float max_action, float* actions_dev, int64_t ld_a, void* stream);
+
 /* ---- introspection (tests, profiling) ----------------------------------- */
 /* Copy a named library-owned scratch array to host (synchronous).  Names:
  * "h0","h1" (activations [4][max_batch][256]), "heads" (partial head sums),

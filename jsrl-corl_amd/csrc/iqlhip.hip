@@ -51,6 +51,10 @@ struct iqlhip_ctx {
   DevScratch sc{};
   float* flat_tmp = nullptr;          // n_params + 4 (debug "grads")
   float* xb = nullptr;                // compact batch [max_batch][row_ld]: rows [s | a | s' | r | d | pad]
+  // iqlhip_actor_forward's own staging (never aliases a training batch): packed states and policy head partials
+  float* xb_act = nullptr;            // [act_cap][row_ld]
+  float* heads_act = nullptr;         // [act_cap][A][NSPLIT]
+  int act_cap = 0;
   int64_t row_ld = 0;
   // actor dropout
   unsigned* drop_bits = nullptr;      // [2][max_batch][8] keep-bits
@@ -157,6 +161,9 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   HIPCHK(dalloc(&c->sc.heads, (size_t)MB * HEAD_LD + (size_t)NSPLIT * MB * A));
   c->row_ld = iqlhip_row_stride(dims->state_dim, A);
   HIPCHK(dalloc(&c->xb, (size_t)MB * c->row_ld));
+  c->act_cap = std::max(MB, IQLHIP_ACT_ROWS);
+  HIPCHK(dalloc(&c->xb_act, (size_t)c->act_cap * c->row_ld));
+  HIPCHK(dalloc(&c->heads_act, (size_t)c->act_cap * A * NSPLIT));
   HIPCHK(hipMalloc((void**)&c->drop_bits, (size_t)2 * MB * 8 * sizeof(unsigned)));
   HIPCHK(hipMemset(c->drop_bits, 0xFF, (size_t)2 * MB * 8 * sizeof(unsigned)));
   HIPCHK(dalloc(&c->sc.slab_a, (size_t)c->n_chunk_max * c->L.n_params));
@@ -215,7 +222,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
-                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb, c->drop_bits};
+                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb, c->xb_act, c->heads_act, c->drop_bits};
   for (void* b : bufs) (void)hipFree(b);
   delete c;
   return IQLHIP_OK;
@@ -357,6 +364,7 @@ static StepParams make_step(const iqlhip_ctx* c, int rows, float inv_batch) {
   p.n_params = L.n_params;
   p.drop_bits = (c->drop_p > 0.f) ? c->drop_bits : nullptr;
   p.drop_scale = (c->drop_p > 0.f) ? 1.f / (1.f - c->drop_p) : 1.f;
+  p.only_inst = -1;
   return p;
 }
 
@@ -652,6 +660,38 @@ extern "C" int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t S, 
   const int nb = (int)std::min<long long>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(iql_rows_gather_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows_dev, (long long)ld, S, A,
                      (const long long*)idx_dev, (long long)n, s, a, r, ns, d);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Policy inference: pack states -> forward of the policy instance only -> tanh / noise / scale / clamp.
+extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows,
+                                    const float* noise_dev, int64_t ld_noise, float max_action, float* actions_dev,
+                                    int64_t ld_a, void* stream) {
+  if (!c || !states_dev || !actions_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (!c->params) return fail(IQLHIP_EINVAL, "iqlhip_bind has not been called");
+  const int S = c->dims.state_dim, A = c->dims.action_dim;
+  if (rows < 0 || rows > c->act_cap) return fail(IQLHIP_EINVAL, "rows %d outside [0, %d]", rows, c->act_cap);
+  if (ld_s < S || ld_a < A || (noise_dev && ld_noise < A)) return fail(IQLHIP_EINVAL, "row stride smaller than the row");
+  if (rows == 0) return IQLHIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int total = rows * (int)c->row_ld;
+  hipLaunchKernelGGL(iql_pack_states_kernel, dim3((total + 255) / 256), dim3(256), 0, st, c->xb_act, (int)c->row_ld, S,
+                     rows, states_dev, (long long)ld_s);
+  StepParams p = make_step(c, rows, 1.f / (float)rows);
+  p.xb = c->xb_act;
+  p.only_inst = 6;
+  p.slot[6] = -1;            // inference keeps no activations
+  p.drop_bits = nullptr;     // eval-mode forward; a training-mode policy with dropout stays on the caller's side
+  p.sc.heads = c->heads_act; // the policy partials of row r land at heads[max_batch * HEAD_LD + r * A * NSPLIT ...]:
+  p.sc.max_batch = 0;        // with max_batch = 0 that is heads_act[r * A * NSPLIT ...]
+  const int n_rt = (rows + RT_ROWS - 1) / RT_ROWS;
+  if (c->precision == 1) hipLaunchKernelGGL(iql_fwd_kernel<true>, dim3(n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
+  else hipLaunchKernelGGL(iql_fwd_kernel<false>, dim3(n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
+  hipLaunchKernelGGL(iql_actor_finish_kernel, dim3((rows * A + 255) / 256), dim3(256), 0, st, c->heads_act, rows, A,
+                     max_action, p.log_std, c->hyper.log_std_min, c->hyper.log_std_max, noise_dev, (long long)ld_noise,
+                     actions_dev, (long long)ld_a);
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }

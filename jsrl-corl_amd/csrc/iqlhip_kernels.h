@@ -117,6 +117,9 @@ struct StepParams {
   // [2 layers][max_batch][8 words] (bit j of word w = unit 32w + j), scale = 1/(1-p); null when off
   const unsigned* drop_bits;
   float drop_scale;
+  // >= 0: forward ONE instance only (grid = n_rt * NSPLIT, blockIdx = row tile * NSPLIT + column slice) — the
+  // policy-inference entry point iqlhip_actor_forward; -1: the training forward over all 7 instances
+  int only_inst;
 };
 
 // Force kernel-argument fields into SGPRs NOW.  hipcc sinks each s_load next to its first use, which
@@ -170,9 +173,9 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
 template <bool BF16>
 __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   const int bid = blockIdx.x;
-  const int inst = bid & 7;
+  const int inst = (p.only_inst >= 0) ? p.only_inst : (bid & 7);
   if (inst >= 7) return;
-  const int rest = bid >> 3;
+  const int rest = (p.only_inst >= 0) ? bid : (bid >> 3);
   const int ns = rest & (NSPLIT - 1);
   const int rt = rest >> 2;
   const int row0 = rt * RT_ROWS;
@@ -1453,6 +1456,34 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
       rr[0] = l[0]; rr[1] = l[1]; rr[2] = l[2]; rr[3] = 0.f;
     }
   }
+}
+
+// Policy inference (GaussianPolicy.act / DeterministicPolicy.act, algorithms/finetune/iql.py:371-379, 404-413):
+// states -> packed rows whose first S columns are the state (the rest zero), then iql_fwd_kernel with
+// only_inst = 6, then this finish kernel over the policy head partials:
+//   action = clamp(max_action * (tanh(pre) [+ exp(clamp(log_std)) * noise]), -max_action, +max_action)
+__global__ void iql_pack_states_kernel(float* xb, int ld, int S, int n, const float* s, long long ld_s) {
+  const int total = n * ld;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int i = e / ld;
+    const int c = e - i * ld;
+    xb[e] = (c < S) ? s[i * ld_s + c] : 0.f;
+  }
+}
+
+__global__ void iql_actor_finish_kernel(const float* heads_pi, int n, int A, float max_action, const float* log_std,
+                                        float ls_min, float ls_max, const float* noise, long long ld_noise,
+                                        float* out, long long ld_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * A) return;
+  const int row = e / A, dd = e - row * A;
+  const f32x4 hp = *(const f32x4*)(heads_pi + (long long)e * NSPLIT);
+  float a = tanh_via_exp(((hp[0] + hp[1]) + hp[2]) + hp[3]);      // same fixed order as the training step (sum4)
+  if (noise != nullptr) {
+    const float sigma = (log_std != nullptr) ? expf(fminf(fmaxf(log_std[dd], ls_min), ls_max)) : 0.f;
+    a = a + sigma * noise[row * ld_noise + dd];
+  }
+  out[row * ld_out + dd] = fminf(fmaxf(a * max_action, -max_action), max_action);
 }
 
 // Five row-major arrays (any strides) -> packed rows [s | a | s' | r | d | pad] of the staging batch.

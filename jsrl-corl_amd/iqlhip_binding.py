@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IQLHIP_LIB", os.path.join(_HERE, "libiqlhip.so"))  # IQLHIP_LIB: diagnostic builds
 
 IQLHIP_HIDDEN = 256
+IQLHIP_ACT_ROWS = 4096      # rows per iqlhip_actor_forward call (include/iqlhip.h)
 NET_V, NET_Q1, NET_Q2, NET_PI = 0, 1, 2, 3
 POLICY_GAUSSIAN, POLICY_DETERMINISTIC = 0, 1
 
@@ -82,6 +83,8 @@ SYMBOLS = [
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("iqlhip_rows_gather", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("iqlhip_actor_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_float,
+                                       C.c_void_p, C.c_int64, C.c_void_p]),
     ("iqlhip_draw_indices", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
     ("iqlhip_debug_read", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),

@@ -3,13 +3,15 @@ state_dict key names (reference: algorithms/finetune/iql.py:305-442), so that
 checkpoints and `isinstance` checks in jsrl_utils.py:593,603 keep working.
 
 These modules only *hold* parameters (as views into the trainer's flat arena
-once an ImplicitQLearning is built) and serve the B=1 env-interaction path
-(`act`).  The training-step arithmetic is NOT done here: it runs in
-libiqlhip.so.  Their forward() is used by the environment loops
-(iql.py:725-738) and by tests.
+once an ImplicitQLearning is built).  The training-step arithmetic is NOT done
+here: it runs in libiqlhip.so, and so does `act()` (the B=1 env-interaction
+path, iql.py:371-379 / 404-413) once a GPU trainer owns the actor; before
+that, or on a CPU device, `act()` and forward() are plain PyTorch exactly as
+in the reference (environment loops iql.py:725-738, tests).
 """
 from __future__ import annotations
 
+import weakref
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -68,6 +70,27 @@ class MLP(nn.Module):
         return self.net(x)
 
 
+# Policy modules whose parameters live in a libiqlhip arena -> the trainer that owns the context (set by
+# ImplicitQLearning on a GPU device).  A registry instead of a module attribute: nothing is added to the
+# module's __dict__/state_dict, and a dead trainer simply disappears.
+_ACTOR_OWNERS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def register_actor_owner(actor: nn.Module, trainer) -> None:
+    _ACTOR_OWNERS[actor] = weakref.ref(trainer)
+
+
+def _hip_owner(actor: nn.Module, device) -> Optional[object]:
+    """The trainer whose HIP context can run this actor's forward for `device`, else None (-> PyTorch path)."""
+    ref = _ACTOR_OWNERS.get(actor)
+    owner = ref() if ref is not None else None
+    if owner is None or not owner.can_act_on(device):
+        return None
+    if actor.training and dropout_p(actor) > 0.0:
+        return None          # training-mode dropout inside act(): the library's inference forward is eval-mode
+    return owner
+
+
 class _PolicyBase(nn.Module):
     def __init__(self, state_dim: int, act_dim: int, max_action: float, hidden_dim: int, n_hidden: int, dropout):
         super().__init__()
@@ -95,6 +118,9 @@ class GaussianPolicy(_PolicyBase):
 
     @torch.no_grad()
     def act(self, state: np.ndarray, device: str = "cpu"):
+        owner = _hip_owner(self, device)
+        if owner is not None:       # fused device path: one forward of the policy MLP + tanh/noise/scale/clamp
+            return owner.act_one(state, self.max_action, sample=self.training)
         obs = torch.tensor(state.reshape(1, -1), device=device, dtype=torch.float32)
         dist = self(obs)
         action = dist.sample() if self.training else dist.mean
@@ -113,6 +139,9 @@ class DeterministicPolicy(_PolicyBase):
 
     @torch.no_grad()
     def act(self, state: np.ndarray, device: str = "cpu"):
+        owner = _hip_owner(self, device)
+        if owner is not None:
+            return owner.act_one(state, self.max_action, sample=False)
         obs = torch.tensor(state.reshape(1, -1), device=device, dtype=torch.float32)
         return self._scaled(self(obs))
 

@@ -27,7 +27,7 @@ from torch.optim.lr_scheduler import CosineAnnealingLR
 
 import iqlhip_binding as hb
 import iqlhip_dp as dp
-from iqlhip_networks import (DeterministicPolicy, GaussianPolicy, LOG_STD_MAX, LOG_STD_MIN, dropout_p,
+from iqlhip_networks import (DeterministicPolicy, GaussianPolicy, LOG_STD_MAX, LOG_STD_MIN, dropout_p, register_actor_owner,
                              linear_layers)
 
 TensorBatch = List[torch.Tensor]
@@ -81,8 +81,10 @@ class ImplicitQLearning:
         self._max_batch = 0
         self._adam_t = {"v": 0, "q": 0, "pi": 0}
         self._hyper_sent = None
+        self._act_bufs = None
         if _is_gpu(device):
             self._attach(max_batch=256)
+            register_actor_owner(self.actor, self)
 
     # ------------------------------------------------------------------ arenas
     def _net_tensors(self) -> Dict[str, Dict[str, nn.Parameter]]:
@@ -590,6 +592,57 @@ class ImplicitQLearning:
         self.total_it = state_dict["total_it"]
 
     # ------------------------------------------------------------------ introspection for tests / bench
+    # ------------------------------------------------------------------ policy inference
+    def can_act_on(self, device) -> bool:
+        """True if the library context can serve actor.act(state, device) (same GPU as the arenas)."""
+        if self._ctx is None or not _is_gpu(device):
+            return False
+        d = torch.device(device)
+        return d.index is None or d.index == self._dev.index
+
+    def actor_forward(self, states: torch.Tensor, sample: bool = False, max_action: Optional[float] = None) -> torch.Tensor:
+        """Batched policy forward on the device: [n, S] float32 -> actions [n, A]
+        = clamp(max_action * (tanh(MLP(s)) [+ sigma * N(0,1) if `sample` and the policy is Gaussian]), +-max_action).
+        The batched form of GaussianPolicy.act / DeterministicPolicy.act (iql.py:371-379, 404-413) for evaluation
+        loops; eval-mode forward (no dropout)."""
+        self._require_gpu()
+        x = self._as_dev(states).reshape(-1, self._S)
+        n = x.shape[0]
+        ma = float(self.max_action if max_action is None else max_action)
+        out = torch.empty((n, self._A), dtype=torch.float32, device=self._dev)
+        noise = None
+        if sample and self._gaussian:
+            noise = torch.randn((n, self._A), dtype=torch.float32, device=self._dev)
+        st = self._stream()
+        cap = max(self._max_batch, hb.IQLHIP_ACT_ROWS)
+        for r0 in range(0, n, cap):
+            r1 = min(n, r0 + cap)
+            nz = noise[r0:r1] if noise is not None else None
+            hb.check(hb.lib().iqlhip_actor_forward(
+                self._ctx, x[r0:r1].data_ptr(), x.stride(0), r1 - r0, nz.data_ptr() if nz is not None else None,
+                self._A, ma, out[r0:r1].data_ptr(), out.stride(0), st))
+        return out
+
+    def act_one(self, state: np.ndarray, max_action: float, sample: bool) -> np.ndarray:
+        """actor.act(state): one state in, one action out, through pinned staging buffers (no per-call allocation)."""
+        self._require_gpu()
+        if self._act_bufs is None:
+            self._act_bufs = (torch.empty((1, self._S), dtype=torch.float32).pin_memory(),
+                              torch.empty((1, self._S), dtype=torch.float32, device=self._dev),
+                              torch.empty((1, self._A), dtype=torch.float32, device=self._dev),
+                              torch.empty((1, self._A), dtype=torch.float32).pin_memory())
+        h_in, d_in, d_out, h_out = self._act_bufs
+        np.copyto(h_in.numpy(), np.asarray(state, dtype=np.float32).reshape(1, -1))
+        with torch.cuda.device(self._dev):
+            d_in.copy_(h_in, non_blocking=True)
+            noise = torch.randn((1, self._A), dtype=torch.float32, device=self._dev) if (sample and self._gaussian) else None
+            hb.check(hb.lib().iqlhip_actor_forward(self._ctx, d_in.data_ptr(), self._S, 1,
+                                                   noise.data_ptr() if noise is not None else None, self._A,
+                                                   float(max_action), d_out.data_ptr(), self._A, self._stream()))
+            h_out.copy_(d_out, non_blocking=True)
+            torch.cuda.current_stream(self._dev).synchronize()
+        return h_out.numpy().flatten().copy()
+
     def set_timing(self, enabled: bool) -> None:
         self._require_gpu()
         hb.check(hb.lib().iqlhip_set_timing(self._ctx, 1 if enabled else 0))

@@ -230,6 +230,21 @@ def iql_step(params, opt, batch, hyper, lrs, dtype=np.float32, grads_override=No
     return newp, newo, info
 
 
+def actor_act(pi: Dict[str, np.ndarray], states: np.ndarray, max_action: float, noise=None, dtype=np.float32):
+    """GaussianPolicy.act / DeterministicPolicy.act restated for a batch of rows (reference
+    algorithms/finetune/iql.py:371-379 and :404-413; mean = MLP with Tanh output :355-361, std :366):
+        a = tanh(MLP(s));  [training-mode Gaussian: a = a + exp(clamp(log_std, -20, 2)) * noise];
+        action = clamp(max_action * a, -max_action, +max_action)
+    `noise` stands for the N(0,1) draw inside dist.sample() (:376).  Dropout is not modelled (eval forward)."""
+    x = np.asarray(states, dtype=dtype).reshape(-1, pi["w0"].shape[1])
+    pre, _, _ = mlp_forward({k: v.astype(dtype) for k, v in pi.items() if k != "log_std"}, x)
+    a = np.tanh(pre)
+    if noise is not None:
+        std = np.exp(np.clip(pi["log_std"].astype(dtype), LOG_STD_MIN, LOG_STD_MAX))
+        a = a + std * np.asarray(noise, dtype=dtype)
+    return np.clip(a * dtype(max_action), -max_action, max_action).astype(dtype)
+
+
 def replay_sample(data: Dict[str, np.ndarray], indices: np.ndarray):
     """ReplayBuffer.sample given the drawn indices: returns s,a,r(B,1),ns,d(B,1)."""
     return (data["observations"][indices], data["actions"][indices],

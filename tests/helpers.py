@@ -16,6 +16,9 @@ SINGLE_STEP_CASES = sorted(
 FREERUN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("g2_"))
 
 
+ACT_CASES = ["g10_act_S17A6_gauss", "g10_act_S29A8_det", "g10_act_S39A28_gauss"]
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     meta = json.loads(str(z["meta"]))
@@ -159,3 +162,11 @@ def check_step_against_golden(z, meta, info, newp, newo, *, grad_rtol=1e-5, para
                     worst[key] = e
                     assert e <= 5e-5, f"{key}: rel-to-max err {e}"
     return worst
+
+
+def act_case_params(meta, z):
+    """Policy parameters of a G10 fixture: synth_params(seed)["pi"] with the fixture's log_std."""
+    pi = synth.synth_params(meta["S"], meta["A"], seed=meta["seed"], gaussian=meta["gaussian"])["pi"]
+    if meta["gaussian"]:
+        pi["log_std"] = z["log_std"].copy()
+    return pi

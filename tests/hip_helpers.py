@@ -31,10 +31,10 @@ def _read_mlp(mod):
     return out
 
 
-def build_hip_trainer(params, S, A, gaussian, hyper, lrs, max_steps, device="cuda", dropout=0.0):
+def build_hip_trainer(params, S, A, gaussian, hyper, lrs, max_steps, device="cuda", dropout=0.0, max_action=1.0):
     qf = iql.TwinQ(S, A)
     vf = iql.ValueFunction(S)
-    actor = (iql.GaussianPolicy if gaussian else iql.DeterministicPolicy)(S, A, 1.0, dropout=dropout)
+    actor = (iql.GaussianPolicy if gaussian else iql.DeterministicPolicy)(S, A, max_action, dropout=dropout)
     _load_mlp(vf.v, params["vf"])
     _load_mlp(qf.q1, params["q1"])
     _load_mlp(qf.q2, params["q2"])
@@ -44,7 +44,7 @@ def build_hip_trainer(params, S, A, gaussian, hyper, lrs, max_steps, device="cud
             actor.log_std.copy_(torch.from_numpy(params["pi"]["log_std"]))
     qf, vf, actor = qf.to(device), vf.to(device), actor.to(device)
     tr = iql.ImplicitQLearning(
-        max_action=1.0, actor=actor, actor_optimizer=torch.optim.Adam(actor.parameters(), lr=lrs["pi"]),
+        max_action=max_action, actor=actor, actor_optimizer=torch.optim.Adam(actor.parameters(), lr=lrs["pi"]),
         q_network=qf, q_optimizer=torch.optim.Adam(qf.parameters(), lr=lrs["q"]),
         v_network=vf, v_optimizer=torch.optim.Adam(vf.parameters(), lr=lrs["v"]),
         iql_tau=hyper["iql_tau"], beta=hyper["beta"], max_steps=max_steps, discount=hyper["discount"],

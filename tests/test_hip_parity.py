@@ -11,7 +11,8 @@ import pytest
 import torch
 
 import synth
-from helpers import (FREERUN_CASES, SINGLE_STEP_CASES, assert_losses, assert_params_after_free_run, batch_from,
+from helpers import (ACT_CASES, FREERUN_CASES, SINGLE_STEP_CASES, act_case_params, assert_losses,
+                     assert_params_after_free_run, batch_from,
                      check_step_against_golden,
                      load_golden, single_step_inputs, sub)
 
@@ -435,3 +436,99 @@ def test_edge_shapes_match_oracle(S, A, B, gaussian):
                 gref = np.abs(info["grads"][n][k])
                 tol = 2e-6 + 3e-4 * np.minimum(1.0, 1e-8 * (2e-6 * max(gref.max(), 1e-30)) / (gref + 1e-8) ** 2)
                 assert np.all(diff <= tol), (n, k, float(diff.max()))
+
+
+# ---------------------------------------------------------------------------
+# Policy inference: iqlhip_actor_forward behind actor.act() / trainer.actor_forward()
+_HYPER = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+_LRS = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+
+
+def _act_trainer(meta, z, dropout=0.0):
+    from hip_helpers import build_hip_trainer
+    params = synth.synth_params(meta["S"], meta["A"], seed=meta["seed"], gaussian=meta["gaussian"])
+    params["pi"] = act_case_params(meta, z)
+    return build_hip_trainer(params, meta["S"], meta["A"], meta["gaussian"], _HYPER, _LRS, 1000, dropout=dropout,
+                             max_action=meta["max_action"])
+
+
+@pytest.mark.parametrize("name", ACT_CASES)
+def test_actor_act_matches_reference(name):
+    """G10: actor.act(state, "cuda") one state at a time (eval mode) and the batched forward, against the
+    reference's GaussianPolicy.act / DeterministicPolicy.act outputs; abs 2e-6 * max_action (tanh at 1 ulp)."""
+    import torch
+    z, meta = load_golden(name)
+    tr = _act_trainer(meta, z)
+    tol = 2e-6 * max(1.0, meta["max_action"])
+    tr.actor.eval()
+    calls = []
+    orig = tr.act_one
+    tr.act_one = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    for i in range(0, meta["n"], 5):
+        a = tr.actor.act(z["states"][i], "cuda")
+        assert a.shape == (meta["A"],) and a.dtype == np.float32
+        assert np.max(np.abs(a - z["actions_eval"][i])) <= tol, i
+    assert len(calls) == len(range(0, meta["n"], 5))          # the library path served every call
+    got = tr.actor_forward(torch.from_numpy(z["states"]).cuda()).cpu().numpy()
+    assert np.max(np.abs(got - z["actions_eval"])) <= tol
+    if meta["gaussian"]:       # training-mode formula with the fixture's noise through the C ABI directly
+        import ctypes as C
+        import iqlhip_binding as hb
+        x = torch.from_numpy(z["states"]).cuda()
+        nz = torch.from_numpy(z["noise"]).cuda()
+        out = torch.empty((meta["n"], meta["A"]), device="cuda")
+        hb.check(hb.lib().iqlhip_actor_forward(tr._ctx, x.data_ptr(), meta["S"], meta["n"], nz.data_ptr(), meta["A"],
+                                               float(meta["max_action"]), out.data_ptr(), meta["A"], tr._stream()))
+        torch.cuda.synchronize()
+        # sigma up to e^2: the noise term amplifies nothing, but |a| reaches ~20 before the clamp -> relative bound
+        assert np.max(np.abs(out.cpu().numpy() - z["actions_noise"])) <= 4e-6 * max(1.0, meta["max_action"])
+
+
+def test_actor_forward_chunks_ragged_and_after_training():
+    """n = 1, a ragged tile, and n > max_batch (chunked) against the oracle with the CURRENT parameters — i.e. the
+    inference path reads the same arena the training step updates."""
+    import torch
+    from oracle import iql_oracle as O
+    from hip_helpers import read_params
+    z, meta = load_golden("g10_act_S17A6_gauss")
+    tr = _act_trainer(meta, z)
+    S, A = meta["S"], meta["A"]
+    data = synth.synth_transitions(256, S, A, seed=5)
+    from hip_helpers import to_torch_batch
+    for _ in range(3):
+        tr.train(to_torch_batch({"s": data["observations"], "a": data["actions"], "r": data["rewards"],
+                                 "ns": data["next_observations"], "d": data["terminals"]}))
+    pi = read_params(tr)["pi"]
+    rng = np.random.default_rng(3)
+    for n in (1, 33, 700, 5000):
+        x = rng.standard_normal((n, S)).astype(np.float32)
+        got = tr.actor_forward(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = O.actor_act(pi, x, meta["max_action"])
+        assert got.shape == (n, A)
+        assert np.max(np.abs(got - want)) <= 2e-6
+    # sampling mode: mean + sigma * N(0,1), clamped; statistics only (device RNG stream)
+    x = np.repeat(rng.standard_normal((1, S)).astype(np.float32), 4096, axis=0)
+    smp = tr.actor_forward(torch.from_numpy(x).cuda(), sample=True).cpu().numpy()
+    mean = O.actor_act(pi, x[:1], meta["max_action"])[0]
+    sigma = np.exp(np.clip(pi["log_std"], -20, 2))
+    free = (np.abs(mean) + 4 * sigma < meta["max_action"]) & (sigma > 1e-3)   # dims the clamp leaves alone
+    assert np.all(np.abs(smp).max(0) <= meta["max_action"])
+    if free.any():
+        assert np.max(np.abs(smp.mean(0)[free] - mean[free]) / (sigma[free] / 64 + 1e-6)) < 5.0
+        assert np.max(np.abs(smp.std(0)[free] / sigma[free] - 1.0)) < 0.1
+
+
+def test_actor_act_falls_back_to_torch_where_the_library_cannot_serve():
+    """CPU device string and training-mode dropout stay on the module's own forward (no library call)."""
+    import torch
+    z, meta = load_golden("g10_act_S29A8_det")
+    tr = _act_trainer(meta, z, dropout=0.1)
+    calls = []
+    tr.act_one = lambda *a, **k: calls.append(1)
+    tr.actor.train()
+    a = tr.actor.act(z["states"][0], "cuda")          # dropout active -> PyTorch path (random masks)
+    assert a.shape == (meta["A"],) and not calls
+    tr.actor.eval()
+    del tr.act_one
+    a = tr.actor.act(z["states"][0], "cuda")
+    assert np.max(np.abs(a - z["actions_eval"][0])) <= 2e-6 * meta["max_action"]

@@ -10,8 +10,8 @@ import numpy as np
 import pytest
 
 import synth
-from helpers import (FREERUN_CASES, SINGLE_STEP_CASES, assert_losses, batch_from, check_step_against_golden,
-                     load_golden, single_step_inputs, sub)
+from helpers import (ACT_CASES, FREERUN_CASES, SINGLE_STEP_CASES, act_case_params, assert_losses, batch_from,
+                     check_step_against_golden, load_golden, single_step_inputs, sub)
 from oracle import iql_oracle as O
 
 
@@ -140,3 +140,19 @@ def test_dropout_step_with_injected_masks_matches_reference(name):
                               target_atol=1e-7)
     bits = synth.pack_keep_bits(k0)
     assert bits.shape == (meta["B"], 8) and ((bits[3, 1] >> 5) & 1) == int(k0[3, 37])
+
+
+@pytest.mark.parametrize("name", ACT_CASES)
+def test_actor_act_matches_reference(name):
+    """G10: the oracle's act() against GaussianPolicy.act / DeterministicPolicy.act of the reference (eval mode, one
+    state per call) and against the training-mode formula with fixture noise."""
+    z, meta = load_golden(name)
+    pi = act_case_params(meta, z)
+    got = O.actor_act(pi, z["states"], meta["max_action"])
+    assert got.shape == z["actions_eval"].shape
+    assert np.max(np.abs(got - z["actions_eval"])) <= 2e-6 * max(1.0, meta["max_action"])
+    assert np.max(np.abs(got)) <= meta["max_action"]
+    if meta["gaussian"]:
+        gn = O.actor_act(pi, z["states"], meta["max_action"], noise=z["noise"])
+        assert np.max(np.abs(gn - z["actions_noise"])) <= 2e-6 * max(1.0, meta["max_action"])
+        assert np.any(np.abs(gn) == meta["max_action"])        # the clamp is exercised (log_std[0] = 3 -> sigma = e^2)

@@ -384,14 +384,58 @@ def statedict_case(ref, outdir):
     print("g6_statedict ok", desc["top_keys"])
 
 
+def act_case(ref, name, S, A, gaussian, max_action, seed, outdir, n=48):
+    """G10: GaussianPolicy.act / DeterministicPolicy.act (finetune/iql.py:371-379, 404-413), one state at a time in
+    eval mode, plus — Gaussian only — the clamp(max_action * (mean + std * noise)) that act() forms in training mode,
+    with the noise drawn here (the reference draws it inside dist.sample(), which no fixture can pin)."""
+    params = synth.synth_params(S, A, seed=seed, gaussian=gaussian)
+    rng = np.random.default_rng(9000 + seed)
+    states = (rng.standard_normal((n, S)) * np.where(np.arange(n)[:, None] % 4 == 3, 6.0, 1.0)).astype(np.float32)
+    actor = (ref.GaussianPolicy if gaussian else ref.DeterministicPolicy)(S, A, max_action)
+    keys = _pi_keys(actor)
+    log_std = None
+    if gaussian:
+        log_std = rng.uniform(-1.0, 0.5, size=A).astype(np.float32)
+        log_std[0] = 3.0            # beyond LOG_STD_MAX = 2 -> clamped
+        if A > 1:
+            log_std[1] = -25.0      # below LOG_STD_MIN = -20 -> clamped
+        params["pi"]["log_std"] = log_std
+    with torch.no_grad():
+        sd = dict(actor.named_parameters())
+        for ours, theirs in keys.items():
+            if ours in params["pi"]:
+                sd[theirs].copy_(torch.from_numpy(params["pi"][ours]))
+    actor.eval()
+    acts = np.stack([actor.act(states[i], "cpu") for i in range(n)]).astype(np.float32)
+    out = {"states": states, "actions_eval": acts}
+    if gaussian:
+        noise = rng.standard_normal((n, A)).astype(np.float32)
+        with torch.no_grad():
+            dist = actor(torch.from_numpy(states))
+            a = dist.mean + dist.stddev * torch.from_numpy(noise)
+            out["actions_noise"] = torch.clamp(max_action * a, -max_action, max_action).numpy().astype(np.float32)
+        out["noise"] = noise
+        out["log_std"] = log_std
+    meta = {"S": S, "A": A, "gaussian": gaussian, "max_action": max_action, "seed": seed, "n": n}
+    np.savez(os.path.join(outdir, name + ".npz"), meta=json.dumps(meta), **out)
+    print(name, "ok; |a|max", float(np.abs(acts).max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default=None, help="generate only the G10 act fixtures ('act')")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(1)
     ref = import_reference(args.ref)
+
+    act_case(ref, "g10_act_S17A6_gauss", 17, 6, True, 1.0, 90, args.out)
+    act_case(ref, "g10_act_S29A8_det", 29, 8, False, 2.5, 91, args.out)
+    act_case(ref, "g10_act_S39A28_gauss", 39, 28, True, 0.5, 92, args.out)
+    if args.only == "act":
+        return
 
     cid = 0
     for (S, A) in ((17, 6), (29, 8), (39, 28)):
