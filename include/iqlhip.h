@@ -180,6 +180,11 @@ int iqlhip_rows_write(float* rows_dev, int64_t ld, int32_t state_dim, int32_t ac
 int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t state_dim, int32_t action_dim,
                        const int64_t* idx_dev, int64_t n, float* s_dev, float* a_dev, float* r_dev, float* ns_dev,
                        float* d_dev, void* stream);
+/* The same sample as whole packed rows: out[i] = rows[idx[i]] (one coalesced row copy per sample).  A batch whose
+ * five pointers are the packed offsets of such a block (a = s + S, s' = s + S + A, r = s + 2S + A, d = r + 1, all
+ * strides = iqlhip_row_stride, 16-byte aligned) is consumed IN PLACE by iqlhip_step / iqlhip_forward_backward. */
+int iqlhip_rows_gather_packed(const float* rows_dev, int64_t ld, const int64_t* idx_dev, int64_t n,
+                              float* out_rows_dev, void* stream);
 /* Device-side index draw used by iqlhip_train_steps, exposed for tests. */
 int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed, uint64_t offset, void* stream);
 

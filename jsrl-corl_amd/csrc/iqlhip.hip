@@ -54,6 +54,7 @@ struct iqlhip_ctx {
   // iqlhip_actor_forward's own staging (never aliases a training batch): packed states and policy head partials
   float* xb_act = nullptr;            // [act_cap][row_ld]
   float* heads_act = nullptr;         // [act_cap][A][NSPLIT]
+  float* losses_host = nullptr;       // pinned landing pad of read_losses (a pageable D2H goes through a bounce copy)
   int act_cap = 0;
   int64_t row_ld = 0;
   // actor dropout
@@ -161,6 +162,7 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   HIPCHK(dalloc(&c->sc.heads, (size_t)MB * HEAD_LD + (size_t)NSPLIT * MB * A));
   c->row_ld = iqlhip_row_stride(dims->state_dim, A);
   HIPCHK(dalloc(&c->xb, (size_t)MB * c->row_ld));
+  HIPCHK(hipHostMalloc((void**)&c->losses_host, 4 * sizeof(float), hipHostMallocDefault));
   c->act_cap = std::max(MB, IQLHIP_ACT_ROWS);
   HIPCHK(dalloc(&c->xb_act, (size_t)c->act_cap * c->row_ld));
   HIPCHK(dalloc(&c->heads_act, (size_t)c->act_cap * A * NSPLIT));
@@ -224,6 +226,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
                   c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb, c->xb_act, c->heads_act, c->drop_bits};
   for (void* b : bufs) (void)hipFree(b);
+  if (c->losses_host) (void)hipHostFree(c->losses_host);
   delete c;
   return IQLHIP_OK;
 }
@@ -289,12 +292,17 @@ static int check_batch(const iqlhip_ctx* c, const iqlhip_batch* b) {
   return IQLHIP_OK;
 }
 
+// True if the five arrays are views of ONE block of packed rows [s|a|s'|r|d|pad] with the library's row stride.
+static bool is_packed(const iqlhip_ctx* c, const iqlhip_batch* b) {
+  const int S = c->dims.state_dim, A = c->dims.action_dim;
+  return b->ld_s == c->row_ld && b->ld_a == c->row_ld && b->ld_r == c->row_ld && b->ld_ns == c->row_ld &&
+         b->ld_d == c->row_ld && b->a_dev == b->s_dev + S && b->ns_dev == b->s_dev + S + A &&
+         b->r_dev == b->s_dev + 2 * S + A && b->d_dev == b->s_dev + 2 * S + A + 1;
+}
+
 // An indexed batch must be row-addressed storage in the packed layout (what ReplayBuffer holds).
 static int check_indexed(const iqlhip_ctx* c, const iqlhip_batch* b) {
-  const int S = c->dims.state_dim, A = c->dims.action_dim;
-  const bool packed = b->ld_s == c->row_ld && b->ld_a == c->row_ld && b->ld_r == c->row_ld && b->ld_ns == c->row_ld &&
-                      b->ld_d == c->row_ld && b->a_dev == b->s_dev + S && b->ns_dev == b->s_dev + S + A &&
-                      b->r_dev == b->s_dev + 2 * S + A && b->d_dev == b->s_dev + 2 * S + A + 1;
+  const bool packed = is_packed(c, b);
   if (!packed) return fail(IQLHIP_EINVAL, "indexed batches must address packed rows [s|a|s'|r|d] with ld=%lld",
                            (long long)c->row_ld);
   if (((uintptr_t)b->s_dev) & 15) return fail(IQLHIP_EINVAL, "packed rows must be 16-byte aligned");
@@ -307,8 +315,15 @@ static void launch_gather(const iqlhip_ctx* c, const float* rows, const long lon
                      c->xb, n);
 }
 
-// Bring the caller's batch into the packed staging buffer xb (the kernels read nothing else).
-static int stage_batch(const iqlhip_ctx* c, const iqlhip_batch* b, hipStream_t st) {
+// Bring the caller's batch into packed rows (the kernels read nothing else): gather by index, or pack five
+// arrays into the staging buffer xb, or — when the caller's arrays already ARE one block of packed rows (what
+// ReplayBuffer.sample returns) — consume them in place.  *xb_out = where the packed batch is.
+static int stage_batch(const iqlhip_ctx* c, const iqlhip_batch* b, hipStream_t st, const float** xb_out) {
+  *xb_out = c->xb;
+  if (!b->idx_dev && is_packed(c, b) && !(((uintptr_t)b->s_dev) & 15)) {
+    *xb_out = b->s_dev;
+    return IQLHIP_OK;
+  }
   if (b->idx_dev) {
     int rc = check_indexed(c, b);
     if (rc) return rc;
@@ -473,10 +488,12 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   int rc = check_batch(c, b);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = stage_batch(c, b, st);
+  const float* xb_cur = nullptr;
+  rc = stage_batch(c, b, st, &xb_cur);
   if (rc) return rc;
   if (c->drop_p > 0.f && !c->drop_inject) launch_dropmask(c, c->drop_seed, c->drop_step++, nullptr, 0, st);
   StepParams p = make_step(c, b->rows, sc->inv_batch);
+  p.xb = xb_cur;
   UpdParams u = make_upd(c, sc, b->rows, nullptr);
   hipEvent_t* ev = nullptr;
   if (c->timing) {
@@ -503,10 +520,12 @@ extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, con
   int rc = check_batch(c, b);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = stage_batch(c, b, st);
+  const float* xb_cur = nullptr;
+  rc = stage_batch(c, b, st, &xb_cur);
   if (rc) return rc;
   if (c->drop_p > 0.f && !c->drop_inject) launch_dropmask(c, c->drop_seed, c->drop_step++, nullptr, 0, st);
   StepParams p = make_step(c, b->rows, sc->inv_batch);
+  p.xb = xb_cur;
   UpdParams u = make_upd(c, sc, b->rows, nullptr);
   launch_fwd(c, p, st);
   launch_bwd(c, p, st);
@@ -527,8 +546,8 @@ extern "C" int iqlhip_apply_update(iqlhip_ctx* c, const float* grads_dev, const 
 
 extern "C" int iqlhip_read_losses(iqlhip_ctx* c, float out[3], void* stream) {
   if (!c || !out) return fail(IQLHIP_EINVAL, "NULL argument");
-  float h[4];
-  HIPCHK(hipMemcpyAsync(h, c->sc.losses, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  float* h = c->losses_host;
+  HIPCHK(hipMemcpyAsync(h, c->sc.losses, 4 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
   return IQLHIP_OK;
@@ -664,6 +683,21 @@ extern "C" int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t S, 
   return IQLHIP_OK;
 }
 
+// ReplayBuffer.sample as ONE coalesced row gather: out[i] = rows[idx[i]] (whole packed rows).
+extern "C" int iqlhip_rows_gather_packed(const float* rows_dev, int64_t ld, const int64_t* idx_dev, int64_t n,
+                                         float* out_rows_dev, void* stream) {
+  if (!rows_dev || !idx_dev || !out_rows_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (n < 0 || ld < 4 || (ld & 3)) return fail(IQLHIP_EINVAL, "bad rows_gather_packed geometry");
+  if ((((uintptr_t)rows_dev) | ((uintptr_t)out_rows_dev)) & 15) return fail(IQLHIP_EINVAL, "rows must be 16-byte aligned");
+  if (n == 0) return IQLHIP_OK;
+  const long long total = (long long)n * (ld / 4);
+  if (total > 0x7fffffffLL) return fail(IQLHIP_EINVAL, "gather too large for one call");
+  hipLaunchKernelGGL(iql_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows_dev,
+                     (long long)ld, (const long long*)idx_dev, out_rows_dev, (int)n);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Policy inference: pack states -> forward of the policy instance only -> tanh / noise / scale / clamp.
 extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows,
@@ -706,13 +740,15 @@ extern "C" int iqlhip_debug_time_kernel(iqlhip_ctx* c, const iqlhip_batch* b, in
   int rc = check_batch(c, b);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = stage_batch(c, b, st);
+  const float* xb_cur = nullptr;
+  rc = stage_batch(c, b, st, &xb_cur);
   if (rc) return rc;
   iqlhip_step_scalars sc;
   memset(&sc, 0, sizeof sc);
   sc.bc2_sqrt[0] = sc.bc2_sqrt[1] = sc.bc2_sqrt[2] = 1.f;
   sc.beta2 = 1.f; sc.eps = 1e-8f; sc.grad_scale = 1.f; sc.inv_batch = 1.f / b->rows;
   StepParams p = make_step(c, b->rows, sc.inv_batch);
+  p.xb = xb_cur;
   UpdParams u = make_upd(c, &sc, b->rows, nullptr);
   u.tau = 0.f; u.one_minus_tau = 1.f;
   hipEvent_t e0, e1;

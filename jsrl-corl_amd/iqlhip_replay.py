@@ -26,6 +26,13 @@ def _is_gpu(device) -> bool:
     return torch.device(device).type == "cuda"
 
 
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream          # (device_index) -> hipStream_t as int
+except AttributeError:                                        # pragma: no cover - older torch
+    def _raw_stream(index: int) -> int:
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 class ReplayBuffer:
     def __init__(self, state_dim: int, action_dim: int, buffer_size: int, device: str = "cpu"):
         self._buffer_size = buffer_size
@@ -67,7 +74,7 @@ class ReplayBuffer:
         return torch.tensor(data, dtype=torch.float32, device=self._device)
 
     def _stream(self):
-        return torch.cuda.current_stream(self._rows.device).cuda_stream
+        return _raw_stream(self._rows.device.index)
 
     def _write_rows(self, row0: int, s, a, r, ns, d) -> None:
         n = s.shape[0]
@@ -113,7 +120,28 @@ class ReplayBuffer:
     def sample_indices(self, batch_size: int) -> torch.Tensor:
         """The reference's host index draw (global numpy RNG), as a device int64 tensor."""
         indices = np.random.randint(0, self._index_bound(), size=batch_size)
-        return torch.from_numpy(indices).to(self._rows.device, non_blocking=False)
+        if not self._gpu:
+            return torch.from_numpy(indices)
+        # H2D through pinned staging buffers: a ring of 4, each guarded by an event so that a buffer is never
+        # rewritten while its copy may still be queued behind earlier work on the stream
+        ring = getattr(self, "_idx_ring", None)
+        if ring is None or ring[0][0].shape[0] < batch_size:
+            ring = [(torch.empty(max(batch_size, 256), dtype=torch.int64).pin_memory(), torch.cuda.Event())
+                    for _ in range(4)]
+            self._idx_ring, self._idx_slot = ring, 0
+        host, done = ring[self._idx_slot]
+        self._idx_slot = (self._idx_slot + 1) % len(ring)
+        done.synchronize()            # no-op unless this slot's previous copy has not run yet
+        host.numpy()[:batch_size] = indices
+        dev = self._rows.device
+        if torch.cuda.current_device() == dev.index:
+            dev_idx = host[:batch_size].to(dev, non_blocking=True)
+            done.record()
+        else:
+            with torch.cuda.device(dev):
+                dev_idx = host[:batch_size].to(dev, non_blocking=True)
+                done.record()
+        return dev_idx
 
     def gather(self, idx: torch.Tensor) -> TensorBatch:
         n = idx.shape[0]
@@ -123,6 +151,19 @@ class ReplayBuffer:
             return [rows[:, :S].contiguous(), rows[:, S: S + A].contiguous(),
                     rows[:, 2 * S + A: 2 * S + A + 1].contiguous(), rows[:, S + A: 2 * S + A].contiguous(),
                     rows[:, 2 * S + A + 1: 2 * S + A + 2].contiguous()]
+        # one coalesced copy of whole packed rows; the five tensors of the reference's contract are views of that
+        # block (shapes as in iql.py:173-177, row stride = the packed stride) — ImplicitQLearning.train() hands
+        # such a block to the library in place, with no re-packing
+        block = torch.empty((n, self._ld), dtype=torch.float32, device=self._rows.device)
+        hb.check(hb.lib().iqlhip_rows_gather_packed(self._rows.data_ptr(), self._ld, idx.data_ptr(), n,
+                                                    block.data_ptr(), self._stream()))
+        return [block[:, :S], block[:, S: S + A], block[:, 2 * S + A: 2 * S + A + 1], block[:, S + A: 2 * S + A],
+                block[:, 2 * S + A + 1: 2 * S + A + 2]]
+
+    def gather_split(self, idx: torch.Tensor) -> TensorBatch:
+        """The same sample as five separate contiguous tensors (iqlhip_rows_gather)."""
+        n = idx.shape[0]
+        S, A = self._state_dim, self._action_dim
         dev = self._rows.device
         out = [torch.empty((n, S), dtype=torch.float32, device=dev),
                torch.empty((n, A), dtype=torch.float32, device=dev),

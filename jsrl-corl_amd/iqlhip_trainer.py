@@ -39,6 +39,13 @@ def _is_gpu(device) -> bool:
     return torch.device(device).type == "cuda"
 
 
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream          # (device_index) -> hipStream_t as int
+except AttributeError:                                        # pragma: no cover - older torch
+    def _raw_stream(index: int) -> int:
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 def _mlp_tensors(module: nn.Module) -> Dict[str, nn.Parameter]:
     lin = linear_layers(module)
     if len(lin) != 3:
@@ -293,26 +300,50 @@ class ImplicitQLearning:
             hb.check(hb.lib().iqlhip_set_hyper(self._ctx, C.byref(h)))
             self._hyper_sent = self._hyper_tuple()
         # actor dropout follows the module's mode, like nn.Dropout (active in train(), off in eval())
-        p_eff = float(dropout_p(self.actor)) if self.actor.training else 0.0
+        p_eff = self._actor_dropout_p() if self.actor.training else 0.0
         if p_eff != self._dropout_sent:
             rank = torch.distributed.get_rank(self._dp_group) if self._dp_world > 1 else 0
             hb.check(hb.lib().iqlhip_set_dropout(self._ctx, p_eff, dp.rank_seed(torch.initial_seed(), rank)))
             self._dropout_sent = p_eff
 
+    def _actor_dropout_p(self) -> float:
+        """max p over the actor's nn.Dropout layers; the layer list is cached (walking named_modules costs ~13 us a
+        step), the p values are read live."""
+        mods = getattr(self, "_actor_dropouts", None)
+        if mods is None or self._actor_dropouts_of is not self.actor:
+            mods = [m for m in self.actor.modules() if isinstance(m, nn.Dropout)]
+            self._actor_dropouts, self._actor_dropouts_of = mods, self.actor
+        return float(max((m.p for m in mods), default=0.0))
+
     def _stream(self):
-        return torch.cuda.current_stream(self._dev).cuda_stream
+        # the raw handle of torch's CURRENT stream on our device (torch.cuda.current_stream() builds a Stream
+        # object: ~4 us per call, three calls per step)
+        return _raw_stream(self._dev.index)
 
     def _as_dev(self, t: torch.Tensor) -> torch.Tensor:
         if t.device != self._dev or t.dtype != torch.float32:
             t = t.to(self._dev, torch.float32)
         return t.contiguous()
 
+    def _rows_of(self, t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+        """(tensor on our device, row stride in floats).  Row-strided views (what ReplayBuffer.sample returns: five
+        views of one packed block) are passed through as they are — the library consumes such a block in place."""
+        if t.device != self._dev or t.dtype != torch.float32:
+            t = t.to(self._dev, torch.float32)
+        if t.dim() == 2 and t.stride(0) >= t.shape[1] and (t.shape[1] == 1 or t.stride(1) == 1):
+            return t, t.stride(0)
+        if t.dim() == 1 and t.stride(0) >= 1:
+            return t, t.stride(0)
+        t = t.contiguous()
+        return t, (t.shape[1] if t.dim() == 2 else 1)
+
     def _batch_struct(self, batch: TensorBatch):
         observations, actions, rewards, next_observations, dones = batch
         if isinstance(self.actor, DeterministicPolicy) or not self._gaussian:
             if actions.dim() != 2 or actions.shape[1] != self._A:
                 raise RuntimeError("Actions shape missmatch")
-        keep = [self._as_dev(x) for x in (observations, actions, rewards, next_observations, dones)]
+        rows = [self._rows_of(x) for x in (observations, actions, rewards, next_observations, dones)]
+        keep = [t for t, _ in rows]
         o, a, r, no, d = keep
         B = o.shape[0]
         if o.dim() != 2 or o.shape[1] != self._S or tuple(no.shape) != (B, self._S) or tuple(a.shape) != (B, self._A):
@@ -320,7 +351,7 @@ class ImplicitQLearning:
         if r.numel() != B or d.numel() != B:
             raise ValueError("rewards / dones must have one element per row")
         b = hb.Batch(o.data_ptr(), a.data_ptr(), r.data_ptr(), no.data_ptr(), d.data_ptr(),
-                     self._S, self._A, 1, self._S, 1, None, B)
+                     rows[0][1], rows[1][1], rows[2][1], rows[3][1], rows[4][1], None, B)
         return b, keep, B
 
     # ------------------------------------------------------------------ the step

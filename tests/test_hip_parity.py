@@ -532,3 +532,36 @@ def test_actor_act_falls_back_to_torch_where_the_library_cannot_serve():
     del tr.act_one
     a = tr.actor.act(z["states"][0], "cuda")
     assert np.max(np.abs(a - z["actions_eval"][0])) <= 2e-6 * meta["max_action"]
+
+
+def test_packed_sample_views_equal_contiguous_batches_bitwise():
+    """ReplayBuffer.sample returns five views of one packed block (consumed in place by the step); the same rows
+    as five contiguous tensors (gather_split), and as oddly strided views, must give bitwise the same step."""
+    import torch
+    import iql
+    from hip_helpers import build_hip_trainer, read_params
+    S, A, N, B = 17, 6, 4096, 256
+    data = synth.synth_transitions(N, S, A, seed=21)
+    buf = iql.ReplayBuffer(S, A, N, "cuda")
+    buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    params = synth.synth_params(S, A, seed=22)
+    trs = [build_hip_trainer(params, S, A, True, _HYPER, _LRS, 1000) for _ in range(3)]
+    np.random.seed(5)
+    for k in range(3):
+        idx = buf.sample_indices(B)
+        views = buf.gather(idx)
+        assert [tuple(v.shape) for v in views] == [(B, S), (B, A), (B, 1), (B, S), (B, 1)]
+        assert views[0].stride(0) == buf._ld and views[0].data_ptr() + 4 * S == views[1].data_ptr()
+        split = buf.gather_split(idx)
+        for v, c in zip(views, split):
+            assert c.is_contiguous() and torch.equal(v, c)
+        wide = [torch.zeros((B, t.shape[1] + 3), device="cuda") for t in split]      # arbitrary row strides
+        for w, c in zip(wide, split):
+            w[:, : c.shape[1]] = c
+        strided = [w[:, : c.shape[1]] for w, c in zip(wide, split)]
+        logs = [trs[0].train(views), trs[1].train(split), trs[2].train(strided)]
+        assert logs[0] == logs[1] == logs[2]
+    p0, p1, p2 = (read_params(t) for t in trs)
+    for net in p0:
+        for t in p0[net]:
+            assert np.array_equal(p0[net][t], p1[net][t]) and np.array_equal(p0[net][t], p2[net][t]), (net, t)
