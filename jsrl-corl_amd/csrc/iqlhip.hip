@@ -71,7 +71,8 @@ struct iqlhip_ctx {
   unsigned long long* stamps = nullptr;  // diagnostic builds (-DIQL_STAMPS): [4096 blocks][16]
   int k_max = 0;
   int n_chunk_max = 0, n_rt_max = 0;
-  size_t lds_fwd = 0, lds_bwd = 0;
+  size_t lds_fwd = 0, lds_fwd_solo = 0, lds_bwd = 0;
+  int n_cus = 256;                    // compute units of the device (MI355X: 256)
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
   hipStream_t cap_stream = nullptr;
   struct CachedGraph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; };
@@ -193,16 +194,23 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   const int kq = dims->state_dim + dims->action_dim;
   const int ks_ = dims->state_dim;   // V / pi layer-0 width; Q nets use kq
   const int w0_lds_k = (kq <= W0_LDS_MAX_K) ? kq : ((ks_ <= W0_LDS_MAX_K) ? ks_ : 0);
-  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * XR_LD_MAX + IQLHIP_MAX_ACTION * 65 + 512 + 16 +
+  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * (int)c->row_ld + ((A * 65 + 3) & ~3) + 512 + 16 +
                         HID * w0_lds_k) * sizeof(float);
+  // One block per CU while the grid fits the chip (co-resident blocks share a CU's L1 and fill rate and only slow
+  // each other down); the exact size — two blocks per CU where it is <= 80 KB — once there are more blocks than CUs.
+  c->lds_fwd_solo = std::max(c->lds_fwd, (size_t)(81 * 1024));
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cus = ncu;
+  }
   const int dyld = ((A + 15) & ~15) + 1;
   const size_t lds_a = (size_t)(4 * 32 * T64_LD + 2 * CHUNK_ROWS * dyld + 32 * 32 + 64) * sizeof(float);
   const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 33 + 4 +
                                 RT_ROWS * XR_LD_MAX) * sizeof(float);
   c->lds_bwd = std::max(lds_a, lds_b);
-  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
   HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
-  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
   HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
   *out = c;
   return IQLHIP_OK;
@@ -409,10 +417,13 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   return u;
 }
 
+static size_t fwd_lds(const iqlhip_ctx* c, int n_blocks) { return (n_blocks <= c->n_cus) ? c->lds_fwd_solo : c->lds_fwd; }
+
 static void launch_fwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
-  if (c->precision == 1) hipLaunchKernelGGL(iql_fwd_kernel<true>, dim3(8 * n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
-  else hipLaunchKernelGGL(iql_fwd_kernel<false>, dim3(8 * n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
+  const int nb = 8 * n_rt * NSPLIT;
+  if (c->precision == 1) hipLaunchKernelGGL(iql_fwd_kernel<true>, dim3(nb), dim3(256), fwd_lds(c, nb), st, p);
+  else hipLaunchKernelGGL(iql_fwd_kernel<false>, dim3(nb), dim3(256), fwd_lds(c, nb), st, p);
 }
 static void launch_bwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
@@ -721,8 +732,8 @@ extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int6
   p.sc.heads = c->heads_act; // the policy partials of row r land at heads[max_batch * HEAD_LD + r * A * NSPLIT ...]:
   p.sc.max_batch = 0;        // with max_batch = 0 that is heads_act[r * A * NSPLIT ...]
   const int n_rt = (rows + RT_ROWS - 1) / RT_ROWS;
-  if (c->precision == 1) hipLaunchKernelGGL(iql_fwd_kernel<true>, dim3(n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
-  else hipLaunchKernelGGL(iql_fwd_kernel<false>, dim3(n_rt * NSPLIT), dim3(256), c->lds_fwd, st, p);
+  if (c->precision == 1) hipLaunchKernelGGL(iql_fwd_kernel<true>, dim3(n_rt * NSPLIT), dim3(256), fwd_lds(c, n_rt * NSPLIT), st, p);
+  else hipLaunchKernelGGL(iql_fwd_kernel<false>, dim3(n_rt * NSPLIT), dim3(256), fwd_lds(c, n_rt * NSPLIT), st, p);
   hipLaunchKernelGGL(iql_actor_finish_kernel, dim3((rows * A + 255) / 256), dim3(256), 0, st, c->heads_act, rows, A,
                      max_action, p.log_std, c->hyper.log_std_min, c->hyper.log_std_max, noise_dev, (long long)ld_noise,
                      actions_dev, (long long)ld_a);

@@ -205,9 +205,12 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   float* H0s = smem;                         // [32][H0_LD]
   float* H1s = H0s + RT_ROWS * H0_LD;        // [32][T64_LD]
   float* Xr = H1s + RT_ROWS * T64_LD;        // [32][ld]  packed rows of this tile
-  float* W2s = Xr + RT_ROWS * XR_LD_MAX;     // [D][64] head weights of this column slice, then b2[D]
-  unsigned* Mk = (unsigned*)(W2s + IQLHIP_MAX_ACTION * 65);   // [2][32][8] dropout keep-bits of the tile
-  float* W0s = W2s + IQLHIP_MAX_ACTION * 65 + 512;   // [256*k0] flat copy of layer-0 weights (when w0_lds); 16-B aligned
+  // (regions sized by the ACTUAL dims, not the limits: at S=17/A=6 the block needs 75 KB instead of 109 KB, so two
+  //  blocks fit a CU's 160 KB when a large batch brings more than one block per CU; host: fwd_lds_floats())
+  float* W2s = Xr + RT_ROWS * ld;            // [D][64] head weights of this column slice, then b2[D] (D <= A)
+  const int w2s_words = (Aact * 65 + 3) & ~3;
+  unsigned* Mk = (unsigned*)(W2s + w2s_words);       // [2][32][8] dropout keep-bits of the tile
+  float* W0s = W2s + w2s_words + 512;        // [256*k0] flat copy of layer-0 weights (when w0_lds); 16-B aligned
   // (no integer casts on LDS pointers: they would demote every access to a flat load, and a flat load
   //  waits vmcnt(0) — it would drain the W1 stream that is meant to stay in flight under layer 0)
 

@@ -56,6 +56,23 @@ def report(name, blocks, labels, sel=None):
     print(f"   {'block total':28s} median {np.median(tot):8.0f}  max {tot.max():8d};  kernel span {int((blk[:, last].astype(np.int64)).max() - first)} cycles")
 
 
+def xcd_spans(name, blocks, last):
+    """s_memtime counters are per XCD: start skew and span are only meaningful inside one XCD (block id % 8)."""
+    out = []
+    for x in range(8):
+        blk = st[blocks[(blocks & 7) == x]]
+        blk = blk[blk[:, 0] > 0]
+        if len(blk) == 0:
+            continue
+        t0 = blk[:, 0].astype(np.int64)
+        t1 = blk[:, last].astype(np.int64)
+        t1 = np.where(t1 > 0, t1, t0)
+        out.append((x, len(blk), int(np.median(t0 - t0.min())), int((t0 - t0.min()).max()), int((t1 - t0).max()), int(t1.max() - t0.min())))
+    print(f"{name}: per XCD (blocks, start skew median/max, longest block, span first-start..last-end)")
+    for o in out:
+        print("   xcd %d: %3d blocks  skew %6d / %6d   longest %6d   span %6d" % o)
+
+
 n_rt = (B + 31) // 32
 fwd_blocks = np.arange(8 * n_rt * 4)
 report("fwd", fwd_blocks, [(1, "prefetch+gather"), (2, "layer0"), (3, "H0 save + layer1"), (4, "H1 save + head")])
@@ -81,6 +98,10 @@ report("bwd (a) dW1 tiles", a_blocks, [(10, "issue loads"), (11, "wait heads + d
                                         (4, "reduce + store (+extras)")])
 report("bwd (b) dH0/dW0", b_blocks, [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"),
                                       (8, "reduce+mask"), (9, "dW0 MFMA + stores")])
+xcd_spans("fwd", fwd_blocks, 4)
+xcd_spans("bwd (a)", a_blocks, 4)
+xcd_spans("bwd (b)", b_blocks, 9)
+xcd_spans("bwd all", bw, 9)
 # clock estimate: cycles per 100 MHz tick over the fwd kernel
 blk = st[fwd_blocks]
 blk = blk[blk[:, 0] > 0]
