@@ -52,6 +52,7 @@ struct iqlhip_ctx {
   float* flat_tmp = nullptr;          // n_params + 4 (debug "grads")
   float* xb = nullptr;                // compact batch [max_batch][row_ld]: rows [s | a | s' | r | d | pad]
   // iqlhip_actor_forward's own staging (never aliases a training batch): packed states and policy head partials
+  float* xb2 = nullptr;               // second staging batch: graph chunks alternate (step k reads one, gathers k+1 into the other)
   float* xb_act = nullptr;            // [act_cap][row_ld]
   float* heads_act = nullptr;         // [act_cap][A][NSPLIT]
   float* losses_host = nullptr;       // pinned landing pad of read_losses (a pageable D2H goes through a bounce copy)
@@ -163,6 +164,7 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   HIPCHK(dalloc(&c->sc.heads, (size_t)MB * HEAD_LD + (size_t)NSPLIT * MB * A));
   c->row_ld = iqlhip_row_stride(dims->state_dim, A);
   HIPCHK(dalloc(&c->xb, (size_t)MB * c->row_ld));
+  HIPCHK(dalloc(&c->xb2, (size_t)MB * c->row_ld));
   HIPCHK(hipHostMalloc((void**)&c->losses_host, 4 * sizeof(float), hipHostMallocDefault));
   c->act_cap = std::max(MB, IQLHIP_ACT_ROWS);
   HIPCHK(dalloc(&c->xb_act, (size_t)c->act_cap * c->row_ld));
@@ -232,7 +234,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
-                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb, c->xb_act, c->heads_act, c->drop_bits};
+                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act, c->heads_act, c->drop_bits};
   for (void* b : bufs) (void)hipFree(b);
   if (c->losses_host) (void)hipHostFree(c->losses_host);
   delete c;
@@ -388,6 +390,7 @@ static StepParams make_step(const iqlhip_ctx* c, int rows, float inv_batch) {
   p.drop_bits = (c->drop_p > 0.f) ? c->drop_bits : nullptr;
   p.drop_scale = (c->drop_p > 0.f) ? 1.f / (1.f - c->drop_p) : 1.f;
   p.only_inst = -1;
+  p.g_rows = nullptr; p.g_ld = c->row_ld; p.g_idx = nullptr; p.g_xb = nullptr; p.g_n = 0;
   return p;
 }
 
@@ -411,8 +414,6 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.sched = nullptr;
   u.sched_idx = 0;
   u.n_upd_blocks = (int)((c->L.n_params / 4 + 255) / 256);
-  u.g_rows = nullptr; u.g_ld = c->row_ld; u.g_idx = nullptr; u.g_xb = c->xb; u.g_n = 0;
-  u.n_gather_blocks = 0;
   u.d_bits = nullptr; u.d_n_words = 2 * c->dims.max_batch * 8; u.d_thresh = 0; u.d_hdr = c->hdr; u.d_k = 0;
   return u;
 }
@@ -447,8 +448,6 @@ static void launch_dropmask(const iqlhip_ctx* c, unsigned long long seed, unsign
 
 static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
   int nb = u.n_upd_blocks;
-  u.n_gather_blocks = u.g_idx ? (u.g_n * (int)(u.g_ld / 4) + 255) / 256 : 0;   // next step's rows
-  nb += u.n_gather_blocks;
   if (u.d_bits) nb += (u.d_n_words + 255) / 256;                               // next step's dropout keep-bits
   if (u.sched) hipLaunchKernelGGL(iql_update_kernel<true>, dim3(nb), dim3(256), 0, st, u);
   else hipLaunchKernelGGL(iql_update_kernel<false>, dim3(nb), dim3(256), 0, st, u);
@@ -619,17 +618,21 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
       hipLaunchKernelGGL(iql_draw_indices_kernel, dim3(nb), dim3(256), 0, cs, c->idx_chunk, n, (long long)size,
                          0ull, 0ull, (const unsigned long long*)c->hdr);
     }
-    launch_gather(c, rows_dev, c->idx_chunk, B, cs);   // rows of step 0; step k+1's ride on update k
+    // rows of step 0 (standalone gather); step k+1's are staged by the idle blocks of forward k into the other of
+    // the two staging buffers (forward k and backward k read buffer k & 1)
+    launch_gather(c, rows_dev, c->idx_chunk, B, cs);
     if (c->drop_p > 0.f) launch_dropmask(c, 0, 0, c->hdr, 0, cs);   // keep-bits of step 0 (seed/step0 from hdr)
     for (int k = 0; k < K; ++k) {
       StepParams p = make_step(c, B, sc[0].inv_batch);
+      p.xb = (k & 1) ? c->xb2 : c->xb;
       UpdParams u = make_upd(c, &sc[0], B, nullptr);
       u.sched = c->sched;
       u.sched_idx = k;
       u.loss_ring = c->loss_ring;
       u.ring_slot = k;
       if (k + 1 < K) {
-        u.g_rows = rows_dev; u.g_idx = c->idx_chunk + (long long)(k + 1) * B; u.g_n = B;
+        p.g_rows = rows_dev; p.g_idx = c->idx_chunk + (long long)(k + 1) * B; p.g_n = B;
+        p.g_xb = (k & 1) ? c->xb : c->xb2;
         if (c->drop_p > 0.f) { u.d_bits = c->drop_bits; u.d_thresh = drop_thresh(c->drop_p); u.d_k = k + 1; }
       }
       launch_fwd(c, p, cs);

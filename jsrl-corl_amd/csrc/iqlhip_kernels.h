@@ -120,6 +120,14 @@ struct StepParams {
   // >= 0: forward ONE instance only (grid = n_rt * NSPLIT, blockIdx = row tile * NSPLIT + column slice) — the
   // policy-inference entry point iqlhip_actor_forward; -1: the training forward over all 7 instances
   int only_inst;
+  // next step's batch (hipGraph chunks): the forward's idle blocks (blockIdx & 7 == 7, one per row tile and column
+  // slice) copy rows[idx[r]] -> g_xb[r] (whole padded rows) into the OTHER staging buffer while the 7 instances run.
+  // In the update kernel the two dependent HBM round trips (index, then row) stretched that kernel by ~0.8 us.
+  const float* g_rows;
+  long long g_ld;
+  const long long* g_idx;   // nullable: nothing to gather
+  float* g_xb;
+  int g_n;
 };
 
 // Force kernel-argument fields into SGPRs NOW.  hipcc sinks each s_load next to its first use, which
@@ -167,6 +175,17 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
 }
 
 // ---------------------------------------------------------------------------
+// rows[idx[r]] -> xb[r], r < n: one float4 per thread-iteration (rows are 16-B aligned, ld % 4 == 0)
+__device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld, const long long* idx, float* xb,
+                                                 int n, int first, int stride) {
+  const int q = (int)(ld >> 2);
+  const int total = n * q;
+  for (int e = first; e < total; e += stride) {
+    const int r = e / q, c4 = e - r * q;
+    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = *(const f32x4*)(rows + idx[r] * ld + 4 * c4);
+  }
+}
+
 // Forward: block = (instance, row tile of 32 rows, column slice ns of 64 hidden-1 units).
 // grid = 8 * n_rt * NSPLIT; blockIdx & 7 = instance (7 = idle) so that the
 // blocks of one instance share an XCD and hence one L2 copy of its weights.
@@ -174,8 +193,11 @@ template <bool BF16>
 __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   const int bid = blockIdx.x;
   const int inst = (p.only_inst >= 0) ? p.only_inst : (bid & 7);
-  if (inst >= 7) return;
   const int rest = (p.only_inst >= 0) ? bid : (bid >> 3);
+  if (inst >= 7) {     // the idle eighth of the grid stages the NEXT step's rows (graph chunks), else exits
+    if (p.g_idx) gather_rows_flat(p.g_rows, p.g_ld, p.g_idx, p.g_xb, p.g_n, rest * 256 + (int)threadIdx.x, (int)(gridDim.x >> 3) * 256);
+    return;
+  }
   const int ns = rest & (NSPLIT - 1);
   const int rt = rest >> 2;
   const int row0 = rt * RT_ROWS;
@@ -1244,15 +1266,8 @@ struct UpdParams {
   int batch_rows;
   const iqlhip_step_scalars* sched;  // when non-null the scalars of this launch are sched[sched_idx]
   int sched_idx;                     // (hipGraph replay: kernel arguments are frozen, the table is not)
-  // next step's batch: extra blocks copy rows[idx[r]] -> xb[r] (whole padded rows, float4)
   int n_upd_blocks;
-  const float* g_rows;
-  long long g_ld;
-  const long long* g_idx;   // nullable: no gather blocks
-  float* g_xb;
-  int g_n;
-  // next step's dropout keep-bits: further extra blocks (after the gather blocks)
-  int n_gather_blocks;
+  // next step's dropout keep-bits: extra blocks after the optimizer blocks
   unsigned* d_bits;         // nullable: no mask blocks
   int d_n_words;
   unsigned d_thresh;
@@ -1346,17 +1361,6 @@ __global__ __launch_bounds__(256) void iql_dropmask_kernel(unsigned* bits, int n
   dropmask_words(bits, n_words, thresh, seed, step, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-// rows[idx[r]] -> xb[r], r < n: one float4 per thread-iteration (rows are 16-B aligned, ld % 4 == 0)
-__device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld, const long long* idx, float* xb,
-                                                 int n, int first, int stride) {
-  const int q = (int)(ld >> 2);
-  const int total = n * q;
-  for (int e = first; e < total; e += stride) {
-    const int r = e / q, c4 = e - r * q;
-    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = *(const f32x4*)(rows + idx[r] * ld + 4 * c4);
-  }
-}
-
 __global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long long ld, const long long* idx,
                                                          float* xb, int n) {
   gather_rows_flat(rows, ld, idx, xb, n, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
@@ -1386,16 +1390,12 @@ __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, floa
 template <bool FROM_TABLE>
 __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
   if ((int)blockIdx.x >= u.n_upd_blocks) {
-    // extra blocks: stage the next step's rows (and dropout keep-bits) while the optimizer blocks run
-    const int gb = (int)blockIdx.x - u.n_upd_blocks;
-    if (gb < u.n_gather_blocks) {
-      gather_rows_flat(u.g_rows, u.g_ld, u.g_idx, u.g_xb, u.g_n, gb * 256 + threadIdx.x, u.n_gather_blocks * 256);
-    } else {
-      const int mb = gb - u.n_gather_blocks;
-      const int nmb = (int)gridDim.x - u.n_upd_blocks - u.n_gather_blocks;
-      dropmask_words(u.d_bits, u.d_n_words, u.d_thresh, u.d_hdr[1] ^ 0x5EEDD120ull,
-                     u.d_hdr[3] + (unsigned long long)u.d_k, mb * 256 + threadIdx.x, nmb * 256);
-    }
+    // extra blocks: the next step's dropout keep-bits while the optimizer blocks run (the next step's ROWS are
+    // staged by the forward kernel's idle blocks, see StepParams::g_idx)
+    const int mb = (int)blockIdx.x - u.n_upd_blocks;
+    const int nmb = (int)gridDim.x - u.n_upd_blocks;
+    dropmask_words(u.d_bits, u.d_n_words, u.d_thresh, u.d_hdr[1] ^ 0x5EEDD120ull,
+                   u.d_hdr[3] + (unsigned long long)u.d_k, mb * 256 + threadIdx.x, nmb * 256);
     return;
   }
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;

@@ -23,4 +23,15 @@ for k, c in out.items():
     w_avg = sum(ws) / len(ws) if ws else None
     res[k] = {"launches": max(len(fs), len(ws)), "FETCH_SIZE_KiB_avg": f_avg, "WRITE_SIZE_KiB_avg": w_avg,
               "hbm_bytes_per_launch_corrected": (None if f_avg is None or w_avg is None else (2 * f_avg + w_avg) * 1024)}
+    # SQ pass (per launch averages; SQ_* are summed over the chip's SIMDs/CUs as rocprofv3 reports them)
+    sq = {n: sum(v) / len(v) for n, v in c.items() if n.startswith(("SQ_", "GRBM_")) and v}
+    if sq:
+        res[k]["sq_per_launch"] = sq
+        busy, mf = sq.get("SQ_BUSY_CYCLES"), sq.get("SQ_VALU_MFMA_BUSY_CYCLES")
+        wc = sq.get("SQ_WAVE_CYCLES")
+        if wc:
+            res[k]["wave_cycle_split"] = {n: sq[n] / wc for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if n in sq}
+        if mf is not None and sq.get("GRBM_GUI_ACTIVE"):
+            # MFMA pipe busy cycles summed over the SIMDs that report / (kernel cycles x 256 CUs x 4 SIMDs)
+            res[k]["mfma_busy_over_gui_active_x1024"] = mf / (sq["GRBM_GUI_ACTIVE"] * 1024.0)
 print(json.dumps(res, indent=1))
