@@ -162,14 +162,18 @@ def main():
         # HBM-side bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950
         # correction; tools/pmc_traffic.py).  Only valid for the default workload.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and (S, A, B) == (17, 6, 256):
+        traffic, mfma_util = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
+        if os.path.exists(pmc) and (S, A, B) == (17, 6, 256) and args.precision == "f32":
             with open(pmc) as fh:
-                traffic = json.load(fh).get("iql_bwd_kernel", {}).get("hbm_bytes_per_launch_corrected")
+                for name, rec in json.load(fh).items():
+                    if "iql_bwd_kernel" in name:
+                        traffic = rec.get("hbm_bytes_per_launch_corrected")
+                        mfma_util = rec.get("mfma_util")      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)
         roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": None if traffic is None else round(traffic),
+                "mfma_util_pmc": None if mfma_util is None else round(mfma_util, 4),
                 "flops_per_launch": f_bwd, "avg_launch_us": round(t_bwd, 3),
                 "kernel_us": {"iql_fwd_kernel": round(t_fwd, 3), "iql_bwd_kernel": round(t_bwd, 3),
                               "iql_update_kernel": round(t_upd, 3)},

@@ -9,7 +9,15 @@ import sys
 from collections import defaultdict
 
 out = defaultdict(lambda: defaultdict(list))
-for d in sys.argv[1:]:
+args = sys.argv[1:]
+avg_ns = {}
+if "--stats" in args:          # kernel_stats.csv of the --kernel-trace --stats pass: average duration per kernel
+    i = args.index("--stats")
+    for r in csv.DictReader(open(args[i + 1])):
+        avg_ns[r["Name"].split("(")[0]] = float(r["AverageNs"])
+    del args[i:i + 2]
+CLK_GHZ, N_SIMD = 2.4, 1024    # MI355X: 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)
+for d in args:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             out[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -31,7 +39,10 @@ for k, c in out.items():
         wc = sq.get("SQ_WAVE_CYCLES")
         if wc:
             res[k]["wave_cycle_split"] = {n: sq[n] / wc for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if n in sq}
-        if mf is not None and sq.get("GRBM_GUI_ACTIVE"):
-            # MFMA pipe busy cycles summed over the SIMDs that report / (kernel cycles x 256 CUs x 4 SIMDs)
-            res[k]["mfma_busy_over_gui_active_x1024"] = mf / (sq["GRBM_GUI_ACTIVE"] * 1024.0)
+        if mf is not None and k in avg_ns:
+            # MfmaUtil: MFMA-pipe busy cycles summed over all SIMDs / (SIMDs x kernel duration x clock); the duration is
+            # the un-instrumented average of the --stats pass (counter passes serialise and stretch the kernels)
+            res[k]["avg_ns_stats_pass"] = avg_ns[k]
+            res[k]["mfma_busy_cycles_per_simd"] = mf / N_SIMD
+            res[k]["mfma_util"] = mf / (N_SIMD * avg_ns[k] * CLK_GHZ)
 print(json.dumps(res, indent=1))

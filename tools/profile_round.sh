@@ -18,8 +18,8 @@ echo "write pass done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o s -- python3 "$ROOT/bench.py" --steps 2000 --warmup 100 --no-cpu-baseline > "$OUT/pmc_sq.json" 2> "$OUT/pmc_sq.err"
 echo "sq pass done"
 cd "$ROOT"
-python3 tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" > "$OUT/pmc_summary.json"
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+python3 tools/pmc_traffic.py --stats "$OUT/kernel_stats.csv" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" > "$OUT/pmc_summary.json"
 # keep the merge-back small: drop the raw traces, keep summaries
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -delete
