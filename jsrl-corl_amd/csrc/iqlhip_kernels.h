@@ -980,7 +980,13 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     RowIn in;
     const int prow = min(row0 + (tid & 31), B - 1);
     const float lsr = pi_ls_issue(p);
-    row_issue(p, (net == IQLHIP_NET_PI) ? -1 : net, prow, in);      // (the policy's own inputs: below)
+    // the scalar nets' per-row loss inputs are consumed by the first 32 threads only: wave 0 alone loads them
+    // (these loads head the in-order queue — issued by all four waves they delayed every load behind them);
+    // the policy's own inputs follow below
+#pragma unroll
+    for (int i = 0; i < 6; ++i) in.h[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    in.r = 0.f; in.d = 0.f;
+    if (wave == 0 && net != IQLHIP_NET_PI) row_issue(p, net, prow, in);
     // policy: the loss arithmetic of the 32 rows is spread over all 256 threads — thread (row tid>>3,
     // dims (tid&7) + 8c) — instead of 32 threads walking all dims while 224 wait at the barrier
     const int prl = tid >> 3, psub = tid & 7;
