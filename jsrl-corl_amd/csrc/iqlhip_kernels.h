@@ -81,10 +81,31 @@ __device__ __forceinline__ unsigned long long iql_memtime() {
 #define STAMP(p, i)                                                                        \
   do {                                                                                     \
     const unsigned long long t_ = iql_memtime();                                           \
-    if ((p).stamps && threadIdx.x == 0) (p).stamps[(long long)blockIdx.x * 16 + (i)] = t_; \
+    if (stamps_ && threadIdx.x == 0) stamps_[(long long)blockIdx.x * 16 + (i)] = t_;       \
+  } while (0)
+// (stamps_ is a LOCAL copy of p.stamps: modifying the by-value kernel-argument struct itself makes the compiler
+//  copy all of it to scratch at entry — 1.1 KB per thread, ~3 us — which is what an earlier stamps build measured)
+#define STAMP_BASE(p, off) unsigned long long* const stamps_ = (p).stamps ? (p).stamps + (off) : nullptr
+// the constant 100 MHz clock shared by the whole chip (s_memtime counters are local and not comparable across blocks)
+__device__ __forceinline__ unsigned long long iql_realtime() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define RT_ENTRY() const unsigned long long rt_entry_ = iql_realtime()
+#define RT_STAMP(p, i, t)                                                                  \
+  do {                                                                                     \
+    if (stamps_ && threadIdx.x == 0) stamps_[(long long)blockIdx.x * 16 + (i)] = (t);      \
   } while (0)
 #else
 #define STAMP(p, i) do {} while (0)
+#define STAMP_BASE(p, off) do {} while (0)
+#define RT_ENTRY() do {} while (0)
+#define RT_STAMP(p, i, t) do {} while (0)
+#define iql_realtime() 0ull
+#define rt_entry_ 0ull
 #endif
 
 // Direct pointers of one MLP (host-built, so a block needs ONE scalar-load round to find its weights).
@@ -191,6 +212,7 @@ __device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld
 // blocks of one instance share an XCD and hence one L2 copy of its weights.
 template <bool BF16>
 __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
+  RT_ENTRY();
   const int bid = blockIdx.x;
   const int inst = (p.only_inst >= 0) ? p.only_inst : (bid & 7);
   const int rest = (p.only_inst >= 0) ? bid : (bid >> 3);
@@ -236,6 +258,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   // (no integer casts on LDS pointers: they would demote every access to a flat load, and a flat load
   //  waits vmcnt(0) — it would drain the W1 stream that is meant to stay in flight under layer 0)
 
+  STAMP_BASE(p, 0);
   STAMP(p, 0);
   // ======== issue every global load of the block.  vmcnt retires in issue order: the small operands of
   // layer 0 go first, the 64 KiB W1 slice last — it keeps streaming while layer 0 runs (no LDS-DMA
@@ -512,6 +535,8 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     }
   }
   STAMP(p, 4);
+  RT_STAMP(p, 14, rt_entry_);
+  RT_STAMP(p, 15, iql_realtime());
 }
 
 // ---------------------------------------------------------------------------
@@ -665,6 +690,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /*>=4 floats*
 //               otherwise              -> (b) block: row tile rt (32 rows), i-slice is (64 cols)
 template <bool BF16>
 __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk, int n_rt) {
+  RT_ENTRY();
   const int bid = blockIdx.x;
   const int x = bid & 7;
   const int net = x & 3;
@@ -699,9 +725,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   if (local >= n_a + 4 * n_rt) return;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-#ifdef IQL_STAMPS
-  if (p.stamps) p.stamps += 2048 * 16;   // second half of the stamp buffer: the forward kernel owns the first
-#endif
+  STAMP_BASE(p, 2048 * 16);   // second half of the stamp buffer: the forward kernel owns the first
   STAMP(p, 0);
 
   if (local < n_a) {
@@ -716,6 +740,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     float* dLs = dYs + CHUNK_ROWS * DYLD;            // [256][DYLD]  (gaussian pi designated block only)
     float* W2s = dLs + CHUNK_ROWS * DYLD;            // [D][32]
     float* rsm = W2s + 32 * 32;                      // [64] small reductions
+    float* wS = rsm + 64;                            // [256] policy: per-row advantage weight
     const bool designated = (jt == 0 && it == 0);
     const bool extras = (it == 0);
     float* slab = p.sc.slab_a + (long long)c * p.n_params;
@@ -725,7 +750,25 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     const int prow = cbase + tid;
     RowIn in;
     const float lsr = pi_ls_issue(p);
-    row_issue(p, net, min(prow, B - 1), in);
+    const bool is_pi = (net == IQLHIP_NET_PI);
+    row_issue(p, is_pi ? -1 : net, min(prow, B - 1), in);     // scalar partials, r, d (the policy needs h[1..3] for w)
+    // Policy: its per-(row, dim) inputs are loaded as (row, dim) work items — thread (r8 = tid >> 3, sub = tid & 7)
+    // takes rows r8 + 32c, c = 0..7, and action dim sub (+ 8e) — so that one load instruction touches 6-8 cache
+    // lines.  With thread = row every such load touched 48-64 lines; the 16 of them held the load queue for 8.5 k
+    // cycles and made the policy's (a) blocks (10-13 us) the long pole of the whole kernel (others: 6-9 us).
+    const int r8 = tid >> 3, sub = tid & 7;
+    const f32x4* hpb = (const f32x4*)(p.sc.heads + MB * HEAD_LD);
+    f32x4 php[8];
+    float pac[8];
+    if (is_pi) {
+      const int dd0 = min(sub, p.A - 1);
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const int rowc = min(cbase + r8 + 32 * cc, B - 1);
+        php[cc] = hpb[rowc * p.A + dd0];
+        pac[cc] = p.xb[rowc * p.ld + p.S + dd0];
+      }
+    }
     float w2pre[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -752,12 +795,77 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         if (e < D * 32) W2s[e] = w2pre[q];
       }
       float lossA = 0.f, lossB = 0.f;
-      float* dyrow = dYs + tid * DYLD;
-      for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
-      float* dlsrow = (designated && net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) ? (dLs + tid * DYLD) : nullptr;
-      if (dlsrow) for (int dd = 0; dd < Dp; ++dd) dlsrow[dd] = 0.f;
       const PiConst pc = pi_consts(p, net, lsr);
-      if (row < B) row_finish(p, net, row, in, pc, dyrow, dlsrow, lossA, lossB);
+      if (!is_pi) {
+        float* dyrow = dYs + tid * DYLD;
+        for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
+        if (row < B) row_finish(p, net, row, in, pc, dyrow, nullptr, lossA, lossB);
+      } else {
+        // phase 1 (thread = row): the advantage weight (iql.py:519); rows >= B get w = 0, hence dY = 0
+        float wrow = 0.f;
+        if (row < B) {
+          const float tq = fminf(sum4(in.h[2]), sum4(in.h[3]));
+          const float u = tq - sum4(in.h[1]);
+          wrow = fminf(expf(p.hy.beta * u), p.hy.exp_adv_max);
+        }
+        wS[tid] = wrow;
+        __syncthreads();                       // (net is block-uniform)
+        // phase 2 (thread = (row, dim)): mean, log-prob term, dL/dpre and dL/dlog_std of every (row, dim)
+        const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
+        const bool want_dls = designated && gauss;
+        const int A = p.A;
+        const float invB = p.inv_batch;
+        for (int e = 0; 8 * e < Dp; ++e) {
+          const int dd = sub + 8 * e;
+          if (8 * e >= A) {                    // padding dims up to Dp: zeros, no loads
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+              dYs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
+              if (want_dls) dLs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
+            }
+            continue;
+          }
+          const int ddc = min(dd, A - 1);
+          const float ivar = __shfl(pc.ivar, ddc);       // lane ddc holds dim ddc's constants; the whole wave is here
+          const float ls = __shfl(pc.ls, ddc);
+          f32x4 hv[8];
+          float acv[8];
+          if (e == 0) {
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) { hv[cc] = php[cc]; acv[cc] = pac[cc]; }
+          } else {                             // action dims >= 8 (wide action spaces): loaded here, 8 at a time
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+              const int rowc = min(cbase + r8 + 32 * cc, B - 1);
+              hv[cc] = hpb[rowc * A + ddc];
+              acv[cc] = p.xb[rowc * p.ld + p.S + ddc];
+            }
+          }
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) {
+            const int rl = r8 + 32 * cc;
+            const float w = wS[rl];
+            float dy = 0.f, dl = 0.f;
+            if (dd < A) {
+              const float mu = tanh_via_exp(sum4(hv[cc]));
+              const float diff = acv[cc] - mu;
+              float dmu;
+              if (gauss) {
+                const float q = diff * diff * ivar;
+                lossA += w * (0.5f * q + ls + 0.918938533204672742f);  // w * -log N(a; mu, sigma), per dim
+                dmu = (-(w * diff) * ivar) * invB;
+                dl = w * (1.f - q);
+              } else {
+                lossA += w * (diff * diff);
+                dmu = (-2.f * w * diff) * invB;
+              }
+              dy = dmu * (1.f - mu * mu);
+            }
+            dYs[rl * DYLD + dd] = dy;
+            if (want_dls) dLs[rl * DYLD + dd] = dl;
+          }
+        }
+      }
       STAMP(p, 11);
       if (designated) {
         const float sA = block_sum_256(lossA, rsm);
@@ -955,6 +1063,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       }
     }
     STAMP(p, 4);
+    RT_STAMP(p, 14, rt_entry_);
+    RT_STAMP(p, 15, iql_realtime());
     return;
   }
 
@@ -1113,9 +1223,6 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
       *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
-      if (q == 0) STAMP(p, 12);
-      if (q == 3) STAMP(p, 13);
-      if (q == 7) STAMP(p, 14);
     }
     __syncthreads();
     STAMP(p, 6);
@@ -1247,6 +1354,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       if (tid < 16) *(f32x4*)(slabB + HID * k0 + i0 + 4 * tid) = *(const f32x4*)(Tb + 4 * tid);
     }
     STAMP(p, 9);
+    RT_STAMP(p, 14, rt_entry_);
+    RT_STAMP(p, 15, iql_realtime());
   }
 }
 

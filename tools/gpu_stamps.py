@@ -56,6 +56,23 @@ def report(name, blocks, labels, sel=None):
     print(f"   {'block total':28s} median {np.median(tot):8.0f}  max {tot.max():8d};  kernel span {int((blk[:, last].astype(np.int64)).max() - first)} cycles")
 
 
+def realtime_report(name, blocks):
+    """Entry (slot 14) and exit (slot 15) on the chip-wide 100 MHz clock: when blocks start and end relative to the
+    first block of the launch (10 ns ticks -> us)."""
+    blk = st[blocks]
+    blk = blk[(blk[:, 14] > 0) & (blk[:, 15] > 0)]
+    if len(blk) == 0:
+        print(name, "no realtime stamps")
+        return
+    t0 = blk[:, 14].astype(np.int64)
+    t1 = blk[:, 15].astype(np.int64)
+    z = t0.min()
+    q = lambda a, p_: np.percentile(a, p_) / 100.0
+    print(f"{name}: {len(blk)} blocks;  start after first block: median {q(t0 - z, 50):.2f} p90 {q(t0 - z, 90):.2f} max {q(t0 - z, 100):.2f} us;"
+          f"  duration: median {q(t1 - t0, 50):.2f} max {q(t1 - t0, 100):.2f} us;  end after first start: median {q(t1 - z, 50):.2f} "
+          f"p90 {q(t1 - z, 90):.2f} max {q(t1 - z, 100):.2f} us")
+
+
 def xcd_spans(name, blocks, last):
     """s_memtime counters are per XCD: start skew and span are only meaningful inside one XCD (block id % 8)."""
     out = []
@@ -86,22 +103,29 @@ a_blocks = bw[local < 32 * n_chunk]
 b_blocks = bw[(local >= 32 * n_chunk) & (local < per_net)]
 LAB_A = [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
          (4, "reduce + store (+extras)")]
-LAB_B = [(5, "W1 prefetch+gather+dY(32)"), (12, "dH1 q0"), (13, "dH1 q1-3"), (14, "dH1 q4-7"), (6, "dH1 barrier"), (7, "128 MFMA + red write"), (8, "reduce+mask"), (9, "dW0 MFMA + stores")]
+LAB_B = [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"), (8, "reduce+mask"), (9, "dW0 MFMA + stores")]
 if os.environ.get("PER_NET"):
     for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
         isn = (ids & 3) == n
         report(f"bwd (a) net {nm}", bw[(local < 32 * n_chunk) & isn], LAB_A)
         report(f"bwd (b) net {nm}", bw[(local >= 32 * n_chunk) & (local < per_net) & isn], LAB_B)
-    for i, nm in enumerate(("V(s)", "Q1", "Q2", "PI", "V(s')", "Qt1", "Qt2")):
+    for i, nm in enumerate(("V(s')", "V(s)", "Qt1", "Qt2", "Q1", "Q2", "PI")):
         report(f"fwd inst {nm}", fwd_blocks[(fwd_blocks & 7) == i], [(1, "prefetch+gather"), (2, "layer0"), (3, "H0 save + layer1"), (4, "H1 save + head")])
 report("bwd (a) dW1 tiles", a_blocks, [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
                                         (4, "reduce + store (+extras)")])
 report("bwd (b) dH0/dW0", b_blocks, [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"),
                                       (8, "reduce+mask"), (9, "dW0 MFMA + stores")])
-xcd_spans("fwd", fwd_blocks, 4)
-xcd_spans("bwd (a)", a_blocks, 4)
-xcd_spans("bwd (b)", b_blocks, 9)
-xcd_spans("bwd all", bw, 9)
+realtime_report("fwd  all", fwd_blocks[(fwd_blocks & 7) != 7])
+realtime_report("bwd  (a)", a_blocks)
+realtime_report("bwd  (b)", b_blocks)
+realtime_report("bwd  all", bw)
+for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
+    realtime_report(f"bwd (b) {nm}", bw[(local >= 32 * n_chunk) & (local < per_net) & ((ids & 3) == n)])
+    realtime_report(f"bwd (a) {nm}", bw[(local < 32 * n_chunk) & ((ids & 3) == n)])
+    sel = (local < 32 * n_chunk) & ((ids & 3) == n)
+    realtime_report(f"bwd (a) {nm} extras (it==0)", bw[sel & ((local & 3) == 0)])
+for i, nm in enumerate(("V(s')", "V(s)", "Qt1", "Qt2", "Q1", "Q2", "PI")):
+    realtime_report(f"fwd inst {nm}", fwd_blocks[(fwd_blocks & 7) == i])
 # clock estimate: cycles per 100 MHz tick over the fwd kernel
 blk = st[fwd_blocks]
 blk = blk[blk[:, 0] > 0]
