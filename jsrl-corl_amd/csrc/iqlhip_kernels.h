@@ -575,9 +575,15 @@ __device__ __forceinline__ void row_issue(const StepParams& p, int net, int row,
 
 __device__ __forceinline__ float sum4(const f32x4 v) { return ((v[0] + v[1]) + v[2]) + v[3]; }
 
-// tanh(x) = 1 - 2 / (exp(2x) + 1): one expf and one division (absolute error ~1 ulp of 1.0; saturates
-// correctly: exp -> inf gives 1, exp -> 0 gives -1).
-__device__ __forceinline__ float tanh_via_exp(float x) { return 1.f - 2.f / (expf(2.f * x) + 1.f); }
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware transcendentals: exp2 (v_exp_f32, 1 ulp) of 2x*log2(e) and
+// v_rcp_f32 (1 ulp).  Absolute error < 1e-7 (the argument rounding |2x log2e| * 6e-8 is damped by
+// d tanh / d e = 2 / (e + 1)^2); saturates correctly: e -> inf gives 1, e -> 0 gives -1.  The policy blocks of the
+// backward evaluate it 256 x A times EACH (every one needs every row's dY), so libm's expf + IEEE division
+// (~35 instructions) were a measurable part of those blocks — the kernel's long pole.
+__device__ __forceinline__ float tanh_via_exp(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);     // exp(2x)
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
 
 // dL/d(head pre-activation) of `net` for one row -> dyrow[0..D); loss terms:
 //   V: lossA = w*u^2     Q1/Q2: lossA = e1^2, lossB = e2^2     pi: lossA = w*bc
@@ -817,11 +823,13 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         const float invB = p.inv_batch;
         for (int e = 0; 8 * e < Dp; ++e) {
           const int dd = sub + 8 * e;
-          if (8 * e >= A) {                    // padding dims up to Dp: zeros, no loads
+          if (8 * e >= A) {                    // padding dims up to Dp: zeros, no loads; only the dW2 MFMA of
+            if (extras) {                      // the extras blocks reads them
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-              dYs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
-              if (want_dls) dLs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
+              for (int cc = 0; cc < 8; ++cc) {
+                dYs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
+                if (want_dls) dLs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
+              }
             }
             continue;
           }
