@@ -748,7 +748,12 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     float* rsm = W2s + 32 * 32;                      // [64] small reductions
     float* wS = rsm + 64;                            // [256] policy: per-row advantage weight
     const bool designated = (jt == 0 && it == 0);
-    const bool extras = (it == 0);
+    // the column-independent extras of this j tile: db1 by the it == 0 block; dW2 by the it == 0 block when D == 1
+    // (two fmas per row) but by the it == 1 block when D > 1 (policy: 32 MFMAs and an LDS round trip) — both on one
+    // block made the policy's it == 0 blocks the last to finish in the whole kernel
+    const bool do_db1 = (it == 0);
+    const bool do_dw2 = (D == 1) ? (it == 0) : (it == 1);
+    const bool extras = do_db1 || do_dw2;
     float* slab = p.sc.slab_a + (long long)c * p.n_params;
 
     // ---- loads, in the order they are needed (vmcnt retires in issue order): the per-row loss
@@ -824,7 +829,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         for (int e = 0; 8 * e < Dp; ++e) {
           const int dd = sub + 8 * e;
           if (8 * e >= A) {                    // padding dims up to Dp: zeros, no loads; only the dW2 MFMA of
-            if (extras) {                      // the extras blocks reads them
+            if (do_dw2 || want_dls) {          // the block that forms dW2 (and the dlog_std sums) reads them
 #pragma unroll
               for (int cc = 0; cc < 8; ++cc) {
                 dYs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
@@ -922,7 +927,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         const float dy = dYs[(rbase + ks) * DYLD];
         av[ks][0] = (hh[ks][0] > 0.f) ? dy * w2a * dscale : 0.f;
         av[ks][1] = (hh[ks][1] > 0.f) ? dy * w2b * dscale : 0.f;
-        if (extras) {
+        if (do_dw2) {
           dw2a[0] = fmaf(dy, hh[ks][0], dw2a[0]);
           dw2a[1] = fmaf(dy, hh[ks][1], dw2a[1]);
         }
@@ -945,7 +950,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         av[ks][1] = (hh[ks][1] > 0.f) ? av[ks][1] * dscale : 0.f;
       }
     }
-    if (extras) {
+    if (do_db1) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) { db1a[0] += av[ks][0]; db1a[1] += av[ks][1]; }
     }
@@ -994,7 +999,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ndt = Dp >> 4;
-    if (extras && D > 1) {
+    if (do_dw2 && D > 1) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
@@ -1051,7 +1056,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           if (g == 0) ex[(wave * 33 + 1) * 32 + 2 * l15 + ta] = u;
         }
       }
-      if (D > 1) {
+      if (D > 1 && do_dw2) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
           if (dt < ndt)
@@ -1066,8 +1071,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         const int rr = e >> 5, jj = e & 31;
         const float s = (ex[(0 * 33 + rr) * 32 + jj] + ex[(1 * 33 + rr) * 32 + jj]) +
                         (ex[(2 * 33 + rr) * 32 + jj] + ex[(3 * 33 + rr) * 32 + jj]);
-        if (rr == 0) slab[go.b1 + j0 + jj] = s;
-        else slab[go.w2 + (rr - 1) * HID + j0 + jj] = s;
+        if (rr == 0) { if (do_db1) slab[go.b1 + j0 + jj] = s; }
+        else if (do_dw2) slab[go.w2 + (rr - 1) * HID + j0 + jj] = s;
       }
     }
     STAMP(p, 4);
