@@ -205,7 +205,7 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cus = ncu;
   }
-  const int dyld = ((A + 15) & ~15) + 1;
+  const int dyld = ((A + 15) & ~15) + 4;     // (a) blocks: [256][Dp + 4] rows for dY and dlog_std terms
   const size_t lds_a = (size_t)(4 * 32 * T64_LD + 2 * CHUNK_ROWS * dyld + 32 * 32 + 64 + CHUNK_ROWS) * sizeof(float);
   const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 33 + 4 +
                                 RT_ROWS * XR_LD_MAX) * sizeof(float);

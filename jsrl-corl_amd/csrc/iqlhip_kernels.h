@@ -547,30 +547,17 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 struct RowIn {
   f32x4 h[6];       // scalar head partials: inst 0..5 x ns 0..3
   float r, d;
-  f32x4 hp[8];      // pi only: head partials of action dims 0..7 (dims >= 8 are loaded in row_finish)
-  float ac[8];      // pi only: the row's action dims 0..7
 };
 
-// `net` is block-uniform.  The pi inputs are issued here, with the other first-needed loads, because
-// vmcnt retires in issue order: loaded later they would queue behind the block's 96 KiB of tile loads.
-__device__ __forceinline__ void row_issue(const StepParams& p, int net, int row, RowIn& in) {
+// The scalar per-row loss inputs of one row (issue only).  The policy's per-(row, dim) inputs are loaded by the
+// callers as coalesced (row, dim) work items.
+__device__ __forceinline__ void row_issue(const StepParams& p, int row, RowIn& in) {
   const f32x4* h = (const f32x4*)(p.sc.heads + row * HEAD_LD);
 #pragma unroll
   for (int i = 0; i < 6; ++i) in.h[i] = h[i];
   const float* xr = p.xb + row * p.ld + 2 * p.S + p.A;
   in.r = xr[0];
   in.d = xr[1];
-  if (net == IQLHIP_NET_PI) {      // (callers pass -1 when they load the policy inputs themselves)
-    const int A = p.A;
-    const float* arow = p.xb + row * p.ld + p.S;
-    const f32x4* hp = (const f32x4*)(p.sc.heads + p.sc.max_batch * HEAD_LD + row * A * NSPLIT);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int dd = min(j, A - 1);
-      in.hp[j] = hp[dd];
-      in.ac[j] = arow[dd];
-    }
-  }
 }
 
 __device__ __forceinline__ float sum4(const f32x4 v) { return ((v[0] + v[1]) + v[2]) + v[3]; }
@@ -585,11 +572,11 @@ __device__ __forceinline__ float tanh_via_exp(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
-// dL/d(head pre-activation) of `net` for one row -> dyrow[0..D); loss terms:
-//   V: lossA = w*u^2     Q1/Q2: lossA = e1^2, lossB = e2^2     pi: lossA = w*bc
-// For the Gaussian policy dlsrow[dd] (if non-null) receives w*(1 - diff^2/var).
-// Per-action-dim constants of the Gaussian policy (clamped log_std, 1/var): lane dd holds dim dd's.
-// Must be called with ALL lanes of the wave active (row_finish reads them with a lane broadcast).
+// row_finish: dL/d(head pre-activation) of a SCALAR net (V, Q1, Q2) for one row -> dyrow[0]; loss terms:
+//   V: lossA = w*u^2     Q1/Q2: lossA = e1^2, lossB = e2^2
+// (the policy's per-(row, dim) terms are formed in the callers as coalesced work items.)
+// PiConst: per-action-dim constants of the Gaussian policy (clamped log_std, 1/var): lane dd holds dim dd's; callers
+// fetch them with a lane shuffle, so all lanes of the wave must be active at that point.
 struct PiConst { float ls, ivar; };
 // The raw log_std word is loaded by pi_ls_issue() BEFORE the block's big prefetches: vmcnt retires in issue
 // order, so a load issued after them would make the loss arithmetic wait for all of them.
@@ -609,67 +596,17 @@ __device__ __forceinline__ PiConst pi_consts(const StepParams& p, int net, float
   return c;
 }
 
-__device__ __forceinline__ void row_finish(const StepParams& p, int net, int row, const RowIn& in, const PiConst pc,
-                                           float* dyrow, float* dlsrow, float& lossA, float& lossB) {
+__device__ __forceinline__ void row_finish(const StepParams& p, int net, const RowIn& in, float* dyrow,
+                                           float& lossA, float& lossB) {
   const float invB = p.inv_batch;
   lossA = 0.f;
   lossB = 0.f;
-  if (net == IQLHIP_NET_V || net == IQLHIP_NET_PI) {
+  if (net == IQLHIP_NET_V) {
     const float tq = fminf(sum4(in.h[2]), sum4(in.h[3]));
-    const float v = sum4(in.h[1]);
-    const float u = tq - v;
-    if (net == IQLHIP_NET_V) {
-      const float wgt = fabsf(p.hy.iql_tau - ((u < 0.f) ? 1.f : 0.f));
-      lossA = wgt * u * u;
-      dyrow[0] = (-2.f * wgt * u) * invB;
-      return;
-    }
-    const float w = fminf(expf(p.hy.beta * u), p.hy.exp_adv_max);
-    const int A = p.A;
-    const float* arow = p.xb + row * p.ld + p.S;
-    const f32x4* hp = (const f32x4*)(p.sc.heads + p.sc.max_batch * HEAD_LD + row * A * NSPLIT);
-    float bc = 0.f;
-    const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
-    // per-action-dim constants (pc) are the same for every row: lane dd holds dim dd's; they are read with
-    // v_readlane (uniform dd), which ignores EXEC, so partially active waves (ragged batch) are fine.
-    for (int d0 = 0; d0 < A; d0 += 8) {
-      // batch the loads of 8 action dims (unconditional, clamped), then do the arithmetic
-      f32x4 hv[8];
-      float acv[8];
-      if (d0 == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { hv[j] = in.hp[j]; acv[j] = in.ac[j]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int dd = min(d0 + j, A - 1);
-          hv[j] = hp[dd];
-          acv[j] = arow[dd];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int dd = d0 + j;
-        if (dd < A) {
-          const float mu = tanh_via_exp(sum4(hv[j]));
-          const float diff = acv[j] - mu;
-          float dmu;
-          if (gauss) {
-            const float ls = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pc.ls), dd));
-            const float ivar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pc.ivar), dd));
-            const float q = diff * diff * ivar;
-            bc += 0.5f * q + ls + 0.918938533204672742f;  // log(sqrt(2 pi))
-            dmu = (-(w * diff) * ivar) * invB;
-            if (dlsrow) dlsrow[dd] = w * (1.f - q);
-          } else {
-            bc += diff * diff;
-            dmu = (-2.f * w * diff) * invB;
-          }
-          dyrow[dd] = dmu * (1.f - mu * mu);
-        }
-      }
-    }
-    lossA = w * bc;
+    const float u = tq - sum4(in.h[1]);
+    const float wgt = fabsf(p.hy.iql_tau - ((u < 0.f) ? 1.f : 0.f));
+    lossA = wgt * u * u;
+    dyrow[0] = (-2.f * wgt * u) * invB;
     return;
   }
   const float nv = sum4(in.h[0]);
@@ -742,12 +679,13 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     const int j0 = jt * 32, i0 = it * 64;
     const int cbase = c * CHUNK_ROWS;
     float* red = smem;                               // [4][32][T64_LD]
-    float* dYs = red + 4 * 32 * T64_LD;              // [256][DYLD]
-    float* dLs = dYs + CHUNK_ROWS * DYLD;            // [256][DYLD]  (gaussian pi designated block only)
-    float* W2s = dLs + CHUNK_ROWS * DYLD;            // [D][32]
+    const int DYA = Dp + 4;                          // row stride of dYs / dLs here: 16-B aligned rows (float4 reads)
+    float* dYs = red + 4 * 32 * T64_LD;              // [256][DYA]
+    float* dLs = dYs + CHUNK_ROWS * DYA;            // [256][DYA]  (gaussian pi designated block only)
+    float* W2s = dLs + CHUNK_ROWS * DYA;            // [D][32]
     float* rsm = W2s + 32 * 32;                      // [64] small reductions
     float* wS = rsm + 64;                            // [256] policy: per-row advantage weight
-    const bool designated = (jt == 0 && it == 0);
+    const bool designated = (jt == 0 && it == 2);    // db2, dlog_std and the loss sums: a block without other extras
     // the column-independent extras of this j tile: db1 by the it == 0 block; dW2 by the it == 0 block when D == 1
     // (two fmas per row) but by the it == 1 block when D > 1 (policy: 32 MFMAs and an LDS round trip) — both on one
     // block made the policy's it == 0 blocks the last to finish in the whole kernel
@@ -762,7 +700,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     RowIn in;
     const float lsr = pi_ls_issue(p);
     const bool is_pi = (net == IQLHIP_NET_PI);
-    row_issue(p, is_pi ? -1 : net, min(prow, B - 1), in);     // scalar partials, r, d (the policy needs h[1..3] for w)
+    row_issue(p, min(prow, B - 1), in);     // scalar partials, r, d (the policy needs h[1..3] for w)
     // Policy: its per-(row, dim) inputs are loaded as (row, dim) work items — thread (r8 = tid >> 3, sub = tid & 7)
     // takes rows r8 + 32c, c = 0..7, and action dim sub (+ 8e) — so that one load instruction touches 6-8 cache
     // lines.  With thread = row every such load touched 48-64 lines; the 16 of them held the load queue for 8.5 k
@@ -808,9 +746,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       float lossA = 0.f, lossB = 0.f;
       const PiConst pc = pi_consts(p, net, lsr);
       if (!is_pi) {
-        float* dyrow = dYs + tid * DYLD;
+        float* dyrow = dYs + tid * DYA;
         for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
-        if (row < B) row_finish(p, net, row, in, pc, dyrow, nullptr, lossA, lossB);
+        if (row < B) row_finish(p, net, in, dyrow, lossA, lossB);
       } else {
         // phase 1 (thread = row): the advantage weight (iql.py:519); rows >= B get w = 0, hence dY = 0
         float wrow = 0.f;
@@ -832,8 +770,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
             if (do_dw2 || want_dls) {          // the block that forms dW2 (and the dlog_std sums) reads them
 #pragma unroll
               for (int cc = 0; cc < 8; ++cc) {
-                dYs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
-                if (want_dls) dLs[(r8 + 32 * cc) * DYLD + dd] = 0.f;
+                dYs[(r8 + 32 * cc) * DYA + dd] = 0.f;
+                if (want_dls) dLs[(r8 + 32 * cc) * DYA + dd] = 0.f;
               }
             }
             continue;
@@ -874,8 +812,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
               }
               dy = dmu * (1.f - mu * mu);
             }
-            dYs[rl * DYLD + dd] = dy;
-            if (want_dls) dLs[rl * DYLD + dd] = dl;
+            dYs[rl * DYA + dd] = dy;
+            if (want_dls) dLs[rl * DYA + dd] = dl;
           }
         }
       }
@@ -898,8 +836,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         float s = 0.f, sl = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          s += dYs[(lane + 64 * q) * DYLD + dd];
-          if (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) sl += dLs[(lane + 64 * q) * DYLD + dd];
+          s += dYs[(lane + 64 * q) * DYA + dd];
+          if (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) sl += dLs[(lane + 64 * q) * DYA + dd];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); sl += __shfl_xor(sl, o); }
@@ -924,13 +862,36 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       const float w2a = W2s[2 * l15], w2b = W2s[2 * l15 + 1];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        const float dy = dYs[(rbase + ks) * DYLD];
+        const float dy = dYs[(rbase + ks) * DYA];
         av[ks][0] = (hh[ks][0] > 0.f) ? dy * w2a * dscale : 0.f;
         av[ks][1] = (hh[ks][1] > 0.f) ? dy * w2b * dscale : 0.f;
         if (do_dw2) {
           dw2a[0] = fmaf(dy, hh[ks][0], dw2a[0]);
           dw2a[1] = fmaf(dy, hh[ks][1], dw2a[1]);
         }
+      }
+    } else if (D <= 8) {
+      // the common policy widths: the 8 (zero-padded) dY of a row as two float4 LDS reads and the head weights of
+      // this lane's two j in registers — straight-line code instead of a D-trip loop of 18 scalar LDS reads each.
+      // Same fma order as the loop below (padding terms add exact zeros), so the results are bitwise the same.
+      float wa8[8], wb8[8];
+#pragma unroll
+      for (int dd = 0; dd < 8; ++dd) {
+        const f32x2 w = *(const f32x2*)(W2s + min(dd, D - 1) * 32 + 2 * l15);
+        wa8[dd] = (dd < D) ? w[0] : 0.f;
+        wb8[dd] = (dd < D) ? w[1] : 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const f32x4 y0 = *(const f32x4*)(dYs + (rbase + ks) * DYA);
+        const f32x4 y1 = *(const f32x4*)(dYs + (rbase + ks) * DYA + 4);
+        float a0 = y0[0] * wa8[0], a1 = y0[0] * wb8[0];
+#pragma unroll
+        for (int dd = 1; dd < 4; ++dd) { a0 = fmaf(y0[dd], wa8[dd], a0); a1 = fmaf(y0[dd], wb8[dd], a1); }
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) { a0 = fmaf(y1[dd], wa8[4 + dd], a0); a1 = fmaf(y1[dd], wb8[4 + dd], a1); }
+        av[ks][0] = (hh[ks][0] > 0.f) ? a0 * dscale : 0.f;
+        av[ks][1] = (hh[ks][1] > 0.f) ? a1 * dscale : 0.f;
       }
     } else {
 #pragma unroll
@@ -939,7 +900,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         const float wa = W2s[dd * 32 + 2 * l15], wb = W2s[dd * 32 + 2 * l15 + 1];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          const float dy = dYs[(rbase + ks) * DYLD + dd];
+          const float dy = dYs[(rbase + ks) * DYA + dd];
           av[ks][0] = fmaf(dy, wa, av[ks][0]);
           av[ks][1] = fmaf(dy, wb, av[ks][1]);
         }
@@ -1005,7 +966,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           if (dt < ndt) {
-            const float ad = dYs[(rbase + ks) * DYLD + 16 * dt + l15];
+            const float ad = dYs[(rbase + ks) * DYA + 16 * dt + l15];
             acc2[dt][0] = MFMA16(ad, hh[ks][0], acc2[dt][0]);
             acc2[dt][1] = MFMA16(ad, hh[ks][1], acc2[dt][1]);
           }
@@ -1109,7 +1070,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
     for (int i = 0; i < 6; ++i) in.h[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     in.r = 0.f; in.d = 0.f;
-    if (wave == 0 && net != IQLHIP_NET_PI) row_issue(p, net, prow, in);
+    if (wave == 0 && net != IQLHIP_NET_PI) row_issue(p, prow, in);
     // policy: the loss arithmetic of the 32 rows is spread over all 256 threads — thread (row tid>>3,
     // dims (tid&7) + 8c) — instead of 32 threads walking all dims while 224 wait at the barrier
     const int prl = tid >> 3, psub = tid & 7;
@@ -1193,7 +1154,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       float la, lbv;
       float* dyrow = dYs + tid * DYLD;
       for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
-      if (row < B) row_finish(p, net, row, in, pc, dyrow, nullptr, la, lbv);
+      if (row < B) row_finish(p, net, in, dyrow, la, lbv);
     }
     __syncthreads();
     STAMP(p, 5);
