@@ -515,10 +515,9 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     // thread (row rl, sub): units 4 sub..4 sub+3 and 32+4 sub..; its H1 values are read once, not once per dim
     const f32x4 ha = *(const f32x4*)(H1s + rl * T64_LD + 4 * sub);
     const f32x4 hb = *(const f32x4*)(H1s + rl * T64_LD + 32 + 4 * sub);
-    for (int dd = 0; dd < D; ++dd) {
-      const float* w2r = W2s + dd * 64;
-      const f32x4 wa = *(const f32x4*)(w2r + 4 * sub);
-      const f32x4 wb = *(const f32x4*)(w2r + 32 + 4 * sub);
+    if (D == 1) {
+      const f32x4 wa = *(const f32x4*)(W2s + 4 * sub);
+      const f32x4 wb = *(const f32x4*)(W2s + 32 + 4 * sub);
       float acc = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = fmaf(ha[e], wa[e], acc);
@@ -527,10 +526,42 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       acc += __shfl_xor(acc, 1);
       acc += __shfl_xor(acc, 2);
       acc += __shfl_xor(acc, 4);
-      if (ns == 0) acc += W2s[D * 64 + dd];
+      if (ns == 0) acc += W2s[64];
       if (sub == 0 && row < B) {
         if (inst < 6) headsg[row * HEAD_LD + inst * NSPLIT + ns] = acc;
-        else headsg[MB * HEAD_LD + (row * Aact + dd) * NSPLIT + ns] = acc;
+        else headsg[MB * HEAD_LD + row * NSPLIT + ns] = acc;           // a policy with one action dim
+      }
+    } else {
+      // policy head: 8 action dims at a time as straight-line code — 8 independent read -> fma -> shuffle chains
+      // overlap (as a D-trip loop each dim was a serial ~500-cycle step and the policy instance the forward's
+      // long pole); after the reduction every lane of a row group holds all sums and lane `sub` stores dim d0 + sub.
+      // Per dim the arithmetic and its order are unchanged.
+      for (int d0 = 0; d0 < D; d0 += 8) {
+        float accs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* w2r = W2s + min(d0 + j, D - 1) * 64;
+          const f32x4 wa = *(const f32x4*)(w2r + 4 * sub);
+          const f32x4 wb = *(const f32x4*)(w2r + 32 + 4 * sub);
+          float acc = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = fmaf(ha[e], wa[e], acc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = fmaf(hb[e], wb[e], acc);
+          accs[j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          accs[j] += __shfl_xor(accs[j], 1);
+          accs[j] += __shfl_xor(accs[j], 2);
+          accs[j] += __shfl_xor(accs[j], 4);
+        }
+        float mine = accs[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mine = (sub == j) ? accs[j] : mine;
+        const int dd = d0 + sub;
+        if (ns == 0) mine += W2s[D * 64 + min(dd, D - 1)];
+        if (dd < D && row < B) headsg[MB * HEAD_LD + (row * Aact + dd) * NSPLIT + ns] = mine;
       }
     }
   }
