@@ -992,15 +992,23 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int j = 0; j < 2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ndt = Dp >> 4;
     if (do_dw2 && D > 1) {
+      // all 16 LDS operands first, then the MFMAs (a read under a per-iteration `if` was waited for on the spot:
+      // 16 exposed LDS latencies made these blocks the last of the kernel)
+      float ad[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[(rbase + ks) * DYA + l15];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
+        acc2[0][0] = MFMA16(ad[ks], hh[ks][0], acc2[0][0]);
+        acc2[0][1] = MFMA16(ad[ks], hh[ks][1], acc2[0][1]);
+      }
+      if (ndt > 1) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          if (dt < ndt) {
-            const float ad = dYs[(rbase + ks) * DYA + 16 * dt + l15];
-            acc2[dt][0] = MFMA16(ad, hh[ks][0], acc2[dt][0]);
-            acc2[dt][1] = MFMA16(ad, hh[ks][1], acc2[dt][1]);
-          }
+        for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[(rbase + ks) * DYA + 16 + l15];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          acc2[1][0] = MFMA16(ad[ks], hh[ks][0], acc2[1][0]);
+          acc2[1][1] = MFMA16(ad[ks], hh[ks][1], acc2[1][1]);
         }
       }
     }
@@ -1333,6 +1341,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           }
         }
       }
+      STAMP(p, 12);
       // stage the [64 i][k0] tile (and db0[64]) in LDS (the cross-wave buffer is free now), then flat float4 stores
       float* T = red;                 // [64][k0]
       float* Tb = red + 64 * IQLHIP_MAX_INPUT;   // [64]
@@ -1350,6 +1359,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       }
     }
     __syncthreads();
+    STAMP(p, 13);
     {
       const float* T = red;
       const float* Tb = red + 64 * IQLHIP_MAX_INPUT;

@@ -103,7 +103,7 @@ a_blocks = bw[local < 32 * n_chunk]
 b_blocks = bw[(local >= 32 * n_chunk) & (local < per_net)]
 LAB_A = [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
          (4, "reduce + store (+extras)")]
-LAB_B = [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"), (8, "reduce+mask"), (9, "dW0 MFMA + stores")]
+LAB_B = [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"), (8, "reduce+mask"), (12, "dW0: LDS reads + MFMA"), (13, "dW0: stage T + barrier"), (9, "dW0: copy out")]
 if os.environ.get("PER_NET"):
     for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
         isn = (ids & 3) == n
@@ -114,7 +114,7 @@ if os.environ.get("PER_NET"):
 report("bwd (a) dW1 tiles", a_blocks, [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
                                         (4, "reduce + store (+extras)")])
 report("bwd (b) dH0/dW0", b_blocks, [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"),
-                                      (8, "reduce+mask"), (9, "dW0 MFMA + stores")])
+                                      (8, "reduce+mask"), (12, "dW0: LDS reads + MFMA"), (13, "dW0: stage T + barrier"), (9, "dW0: copy out")])
 realtime_report("fwd  all", fwd_blocks[(fwd_blocks & 7) != 7])
 realtime_report("bwd  (a)", a_blocks)
 realtime_report("bwd  (b)", b_blocks)
@@ -123,7 +123,8 @@ for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
     realtime_report(f"bwd (b) {nm}", bw[(local >= 32 * n_chunk) & (local < per_net) & ((ids & 3) == n)])
     realtime_report(f"bwd (a) {nm}", bw[(local < 32 * n_chunk) & ((ids & 3) == n)])
     sel = (local < 32 * n_chunk) & ((ids & 3) == n)
-    realtime_report(f"bwd (a) {nm} extras (it==0)", bw[sel & ((local & 3) == 0)])
+    for itv in range(4):
+        realtime_report(f"bwd (a) {nm} it=={itv}", bw[sel & ((local & 3) == itv)])
 for i, nm in enumerate(("V(s')", "V(s)", "Qt1", "Qt2", "Q1", "Q2", "PI")):
     realtime_report(f"fwd inst {nm}", fwd_blocks[(fwd_blocks & 7) == i])
 # clock estimate: cycles per 100 MHz tick over the fwd kernel
