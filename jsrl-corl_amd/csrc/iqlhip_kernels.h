@@ -1014,7 +1014,10 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     }
     STAMP(p, 3);
 
-    // ---- cross-wave reduction of the 32x64 tile through LDS, then coalesced store
+    // ---- cross-wave reduction of the 32x64 tile through LDS, then coalesced store.  The extras (db1 / dW2 partial
+    // sums of the 4 waves) are staged in the same pass, in the dLs region — only the loss-sum block (it == 2), which
+    // has no extras, ever uses that region — so one barrier serves both reductions.
+    float* ex = dLs;   // [4 waves][(1 + Dp) rows][32 cols]
     {
       float* myred = red + wave * 32 * T64_LD;
 #pragma unroll
@@ -1026,23 +1029,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           *(f32x4*)(myred + jl * T64_LD + 4 * l15) = v;
         }
     }
-    __syncthreads();
-    {
-      float* gw1 = slab + go.w1;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int f = tid + 256 * q;
-        const int jl = f >> 4, i4 = f & 15;
-        f32x4 s = *(const f32x4*)(red + jl * T64_LD + 4 * i4);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + w * 32 * T64_LD + jl * T64_LD + 4 * i4);
-        *(f32x4*)(gw1 + (j0 + jl) * HID + i0 + 4 * i4) = s;
-      }
-    }
     if (extras) {
-      __syncthreads();
-      // db1 and dW2: reduce over g (lanes with equal l15), then over waves via LDS
-      float* ex = red;   // reuse: [4 waves][ (1 + Dp) rows ][32 cols]
+      // db1 and dW2: reduce over g (lanes with equal l15) here, over the waves after the barrier
 #pragma unroll
       for (int ta = 0; ta < 2; ++ta) {
         float v = db1a[ta];
@@ -1066,7 +1054,21 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
               for (int reg = 0; reg < 4; ++reg)
                 ex[(wave * 33 + 1 + 16 * dt + 4 * g + reg) * 32 + 2 * l15 + tb] = acc2[dt][tb][reg];
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    {
+      float* gw1 = slab + go.w1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int f = tid + 256 * q;
+        const int jl = f >> 4, i4 = f & 15;
+        f32x4 s = *(const f32x4*)(red + jl * T64_LD + 4 * i4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + w * 32 * T64_LD + jl * T64_LD + 4 * i4);
+        *(f32x4*)(gw1 + (j0 + jl) * HID + i0 + 4 * i4) = s;
+      }
+    }
+    if (extras) {
       for (int e = tid; e < (1 + D) * 32; e += 256) {
         const int rr = e >> 5, jj = e & 31;
         const float s = (ex[(0 * 33 + rr) * 32 + jj] + ex[(1 * 33 + rr) * 32 + jj]) +
