@@ -207,7 +207,7 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   }
   const int dyld = ((A + 15) & ~15) + 4;     // (a) blocks: [256][Dp + 4] rows for dY and dlog_std terms
   const size_t lds_a = (size_t)(4 * 32 * T64_LD + 2 * CHUNK_ROWS * dyld + 32 * 32 + 64 + CHUNK_ROWS) * sizeof(float);
-  const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 33 + 4 +
+  const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 36 + 4 +
                                 RT_ROWS * XR_LD_MAX) * sizeof(float);
   c->lds_bwd = std::max(lds_a, lds_b);
   HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));

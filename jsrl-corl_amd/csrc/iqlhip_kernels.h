@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   const NetGrad go = p.go[net];
   const int D = np.d;
   const int Dp = (D + 15) & ~15;      // 16 or 32
-  const int DYLD = Dp + 1;
+  const int DYLD = Dp + 4;            // dY row stride in LDS: 16-B aligned rows (float4 reads of a row's dims)
   const float* w2 = np.w2;
   const float* H1g = p.sc.h1 + net * MB * HID;
   const float* H0g = p.sc.h0 + net * MB * HID;
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     float* red = dH1s + RT_ROWS * H0_LD;             // [4][32][T64_LD]
     float* dH0s = red + 4 * 32 * T64_LD;             // [32][T64_LD]
     float* dYs = dH0s + RT_ROWS * T64_LD;            // [32][DYLD]
-    float* Xr = dYs + RT_ROWS * 33;                  // [32][ld] packed rows (parked late); 1056 floats -> 16-B aligned
+    float* Xr = dYs + RT_ROWS * 36;                  // [32][ld] packed rows (parked late); 16-B aligned
 
     // ---- issue every global load of the block, first-needed first (vmcnt retires in issue order)
     RowIn in;
@@ -1210,12 +1210,12 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       } else if (D <= 8) {
         // dYs is zero-filled up to Dp >= 8 and w2v8[j >= D] repeats row D-1: 8 unconditional LDS reads in one
         // batch (a per-dim `if` makes each read -> wait -> fma a serial ~160-cycle step)
-        float dy8[8];
+        const f32x4 ya = *(const f32x4*)(dYs + rl * DYLD), yb = *(const f32x4*)(dYs + rl * DYLD + 4);
+        s = ya[0] * w2v8[0];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dy8[j] = dYs[rl * DYLD + j];
-        s = dy8[0] * w2v8[0];
+        for (int j = 1; j < 4; ++j) s += ya[j] * w2v8[j];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) s += dy8[j] * w2v8[j];
+        for (int j = 0; j < 4; ++j) s += yb[j] * w2v8[4 + j];
       } else {
         s = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int d0 = 0; d0 < D; d0 += 8) {
