@@ -716,12 +716,14 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     float* W2s = dLs + CHUNK_ROWS * DYA;            // [D][32]
     float* rsm = W2s + 32 * 32;                      // [64] small reductions
     float* wS = rsm + 64;                            // [256] policy: per-row advantage weight
-    const bool designated = (jt == 0 && it == 2);    // db2, dlog_std and the loss sums: a block without other extras
+    const bool designated = (jt == 0 && it == 2);    // db2 and dlog_std: a block without other extras
+    const bool loss_block = (jt == 1 && it == 2);    // the loss sums: another one
     // the column-independent extras of this j tile: db1 by the it == 0 block; dW2 by the it == 0 block when D == 1
-    // (two fmas per row) but by the it == 1 block when D > 1 (policy: 32 MFMAs and an LDS round trip) — both on one
-    // block made the policy's it == 0 blocks the last to finish in the whole kernel
+    // (two fmas per row) but, when D > 1 (policy: MFMAs and an LDS round trip), one half of the j columns each by
+    // the it == 1 and it == 3 blocks — all on one block made that block the last to finish in the whole kernel
     const bool do_db1 = (it == 0);
-    const bool do_dw2 = (D == 1) ? (it == 0) : (it == 1);
+    const bool do_dw2 = (D == 1) ? (it == 0) : (it == 1 || it == 3);
+    const int tb_own = (it == 3) ? 1 : 0;            // D > 1: which of a lane's two j columns this block's dW2 covers
     const bool extras = do_db1 || do_dw2;
     float* slab = p.sc.slab_a + (long long)c * p.n_params;
 
@@ -849,7 +851,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         }
       }
       STAMP(p, 11);
-      if (designated) {
+      if (loss_block) {
         const float sA = block_sum_256(lossA, rsm);
         if (net == IQLHIP_NET_V && tid == 0) p.sc.loss_parts[0 * 64 + c] = sA;
         if (net == IQLHIP_NET_PI && tid == 0) p.sc.loss_parts[3 * 64 + c] = sA;
@@ -997,19 +999,16 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       float ad[16];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[(rbase + ks) * DYA + l15];
+      float hsel[16];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        acc2[0][0] = MFMA16(ad[ks], hh[ks][0], acc2[0][0]);
-        acc2[0][1] = MFMA16(ad[ks], hh[ks][1], acc2[0][1]);
-      }
+      for (int ks = 0; ks < 16; ++ks) hsel[ks] = tb_own ? hh[ks][1] : hh[ks][0];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc2[0][0] = MFMA16(ad[ks], hsel[ks], acc2[0][0]);
       if (ndt > 1) {
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[(rbase + ks) * DYA + 16 + l15];
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          acc2[1][0] = MFMA16(ad[ks], hh[ks][0], acc2[1][0]);
-          acc2[1][1] = MFMA16(ad[ks], hh[ks][1], acc2[1][1]);
-        }
+        for (int ks = 0; ks < 16; ++ks) acc2[1][0] = MFMA16(ad[ks], hsel[ks], acc2[1][0]);
       }
     }
     STAMP(p, 3);
@@ -1049,10 +1048,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         for (int dt = 0; dt < 2; ++dt)
           if (dt < ndt)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-              for (int reg = 0; reg < 4; ++reg)
-                ex[(wave * 33 + 1 + 16 * dt + 4 * g + reg) * 32 + 2 * l15 + tb] = acc2[dt][tb][reg];
+            for (int reg = 0; reg < 4; ++reg)
+              ex[(wave * 33 + 1 + 16 * dt + 4 * g + reg) * 32 + 2 * l15 + tb_own] = acc2[dt][0][reg];
       }
     }
     __syncthreads();
@@ -1074,7 +1071,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         const float s = (ex[(0 * 33 + rr) * 32 + jj] + ex[(1 * 33 + rr) * 32 + jj]) +
                         (ex[(2 * 33 + rr) * 32 + jj] + ex[(3 * 33 + rr) * 32 + jj]);
         if (rr == 0) { if (do_db1) slab[go.b1 + j0 + jj] = s; }
-        else if (do_dw2) slab[go.w2 + (rr - 1) * HID + j0 + jj] = s;
+        else if (do_dw2 && (D == 1 || (jj & 1) == tb_own)) slab[go.w2 + (rr - 1) * HID + j0 + jj] = s;
       }
     }
     STAMP(p, 4);

@@ -196,14 +196,16 @@ def test_split_step_equals_fused_step():
             assert np.array_equal(pa[n][k], pb[n][k]), (n, k)
 
 
-def test_train_steps_graph_matches_eager_steps_on_same_indices():
-    """K steps replayed as one hipGraph (device index draw, gather fused into the update kernel) equal
-    K eager steps fed with the same indices — bitwise."""
+@pytest.mark.parametrize("K,B", [(7, 256), (1, 100), (4, 33)])
+def test_train_steps_graph_matches_eager_steps_on_same_indices(K, B):
+    """K steps replayed as one hipGraph (device index draw; the rows of step k+1 staged by the idle blocks of forward
+    k into the other staging buffer) equal K eager steps fed with the same indices — bitwise.  Odd and even K, K = 1,
+    ragged batches."""
     import ctypes as C
     import iql
     import iqlhip_binding as hb
     build, _, _, read_params, _, _ = _hip()
-    S, A, N, B, K = 17, 6, 5000, 256, 7
+    S, A, N = 17, 6, 5000
     params = synth.synth_params(S, A, seed=21)
     hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
     lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
@@ -228,6 +230,9 @@ def test_train_steps_graph_matches_eager_steps_on_same_indices():
     assert g.actor_optimizer.param_groups[0]["lr"] == e.actor_optimizer.param_groups[0]["lr"]
     sd = g.state_dict()
     assert float(sd["q_optimizer"]["state"][0]["step"]) == K
+    # a second chunk on the same trainer continues from the first (graph cache hit, fresh indices)
+    more = g.train_steps(buf, K, B, seed=78)
+    assert more.shape == (K, 3) and np.all(np.isfinite(more)) and g.total_it == 2 * K
 
 
 def test_device_index_draw_is_uniform():
