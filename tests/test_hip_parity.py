@@ -570,3 +570,41 @@ def test_packed_sample_views_equal_contiguous_batches_bitwise():
     for net in p0:
         for t in p0[net]:
             assert np.array_equal(p0[net][t], p1[net][t]) and np.array_equal(p0[net][t], p2[net][t]), (net, t)
+
+
+def test_full_size_buffer_graph_equals_eager_and_reaches_the_last_row():
+    """BASELINE configs[1] geometry (1 M rows x 176 B): the device index draw covers the whole buffer (the last
+    row included over a few chunks' worth of draws), the packed gather reads the right rows at the far end, and
+    graph steps equal eager steps on the same indices — size-independent properties checked at full size."""
+    import iql
+    import iqlhip_binding as hb
+    from hip_helpers import build_hip_trainer, read_params
+    S, A, N, B, K = 17, 6, 1_000_000, 256, 5
+    data = synth.synth_transitions(N, S, A, seed=0)
+    buf = iql.ReplayBuffer(S, A, N, "cuda")
+    buf.load_d4rl_dataset(data)
+    # gather at the extremes against the host arrays
+    idx_np = np.array([0, 1, N - 1, N - 2, N // 2, N - 1], dtype=np.int64)
+    got = buf.gather(torch.from_numpy(idx_np).cuda())
+    for t, key in zip(got, ("observations", "actions", "rewards", "next_observations", "terminals")):
+        want = data[key][idx_np].reshape(len(idx_np), -1)
+        assert np.array_equal(t.cpu().numpy(), want), key
+    # device draw: bounds and coverage of both ends
+    n = 1 << 22
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    hb.check(hb.lib().iqlhip_draw_indices(idx.data_ptr(), n, N, 5, 0, torch.cuda.current_stream().cuda_stream))
+    assert int(idx.min()) == 0 and int(idx.max()) == N - 1
+    # graph == eager on the same index stream
+    params = synth.synth_params(S, A, seed=3)
+    g = build_hip_trainer(params, S, A, True, _HYPER, _LRS, 1000)
+    e = build_hip_trainer(params, S, A, True, _HYPER, _LRS, 1000)
+    losses = g.train_steps(buf, K, B, seed=11)
+    kidx = torch.empty(K * B, dtype=torch.int64, device="cuda")
+    hb.check(hb.lib().iqlhip_draw_indices(kidx.data_ptr(), K * B, N, 11, 0, torch.cuda.current_stream().cuda_stream))
+    for k in range(K):
+        log = e.train(buf.gather(kidx[k * B:(k + 1) * B]))
+        assert [log["value_loss"], log["q_loss"], log["actor_loss"]] == [float(x) for x in losses[k]]
+    pa, pb = read_params(g), read_params(e)
+    for net in pa:
+        for t in pa[net]:
+            assert np.array_equal(pa[net][t], pb[net][t]), (net, t)
