@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* stamps,
 #pragma unroll
   for (int r = 0; r < REPS; ++r) {
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a + (float)i, b, acc[i], 0, 0, 0);   // distinct operands: no CSE across accumulators
   }
   // force completion: read the accumulators
   float s = 0.f;
