@@ -6,6 +6,8 @@ noise on cancelling sums; the oracle itself sits at 1.1e-5 from the reference on
 tensor), post-step parameters abs <= 2e-6, Adam moments rel-to-max <= 5e-5, target
 abs <= 1e-7*scale.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -608,3 +610,42 @@ def test_full_size_buffer_graph_equals_eager_and_reaches_the_last_row():
     for net in pa:
         for t in pa[net]:
             assert np.array_equal(pa[net][t], pb[net][t]), (net, t)
+
+
+def test_online_loop_body_runs_on_the_device_and_keeps_ring_semantics():
+    """The reference's online iteration (iql.py:725-778; configs[2] dims) against a numpy stand-in env: act ->
+    env.step -> add_transition -> sample -> train.  The ring wraps, samples only see written rows, every loss is
+    finite and the rows the buffer holds are the rows that were added."""
+    import iql
+    sys_path_tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_online_loop", os.path.join(sys_path_tools, "gpu_online_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    S, A, ring = 29, 8, 300
+    qf, vf, actor = iql.TwinQ(S, A).cuda(), iql.ValueFunction(S).cuda(), iql.DeterministicPolicy(S, A, 1.0).cuda()
+    tr = iql.ImplicitQLearning(1.0, actor, torch.optim.Adam(actor.parameters(), lr=3e-4), qf,
+                               torch.optim.Adam(qf.parameters(), lr=3e-4), vf, torch.optim.Adam(vf.parameters(), lr=3e-4),
+                               iql_tau=0.9, beta=10.0, max_steps=None, device="cuda")
+    buf = iql.ReplayBuffer(S, A, ring, "cuda")
+    env = mod.ToyEnv(S, A, seed=4)
+    state = env.reset()
+    added = []
+    np.random.seed(2)
+    for it in range(450):                           # 1.5 x the ring: the pointer wraps
+        a = actor.act(state, "cuda")
+        assert a.shape == (A,) and np.all(np.abs(a) <= 1.0)
+        ns, r, d, _ = env.step(a)
+        buf.add_transition(state, a, r, ns, d)
+        added.append((state.copy(), a.copy(), np.float32(r), ns.copy(), np.float32(d)))
+        if it >= 40:
+            log = tr.train([b.to("cuda") for b in buf.sample(64)])
+            assert all(np.isfinite(v) for v in log.values())
+        state = env.reset() if d else ns
+    assert buf._size == ring and buf._pointer == 450 % ring and tr.total_it == 410
+    rows = buf._rows.cpu().numpy()
+    for i in (0, 149, 150, ring - 1):               # row i holds the LAST transition written there
+        k = i + ring if i < 450 - ring else i
+        s_, a_, r_, ns_, d_ = added[k]
+        want = np.concatenate([s_, a_, ns_, [r_, d_]])
+        assert np.array_equal(rows[i, : 2 * S + A + 2], want), i
