@@ -195,10 +195,14 @@ int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed
  * noise_dev == NULL gives the mean (eval mode, or the deterministic policy); with a Gaussian policy in training mode
  * the caller passes standard-normal noise [rows][action_dim] (dist.sample() of iql.py:376).  Dropout is NOT applied
  * (eval-mode forward).  rows <= max(max_batch, IQLHIP_ACT_ROWS) per call.  Uses the bound parameter arena;
- * asynchronous on `stream`. */
+ * asynchronous on `stream`.  states / noise / actions may be device memory or host-mapped (pinned) memory. */
 #define IQLHIP_ACT_ROWS 4096
 int iqlhip_actor_forward(iqlhip_ctx* ctx, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
                          int64_t ld_noise, float max_action, float* actions_dev, int64_t ld_a, void* stream);
+
+/* Block the host until everything queued on `stream` has finished (hipStreamSynchronize): the completion point of
+ * iqlhip_actor_forward when its buffers are host-mapped, i.e. the `.cpu()` of the reference's act() (iql.py:379). */
+int iqlhip_stream_synchronize(void* stream);
 
 /* ---- introspection (tests, profiling) ----------------------------------- */
 /* Copy a named library-owned scratch array to host (synchronous).  Names:

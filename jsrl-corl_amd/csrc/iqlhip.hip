@@ -712,6 +712,11 @@ extern "C" int iqlhip_rows_gather_packed(const float* rows_dev, int64_t ld, cons
   return IQLHIP_OK;
 }
 
+extern "C" int iqlhip_stream_synchronize(void* stream) {
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return IQLHIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Policy inference: pack states -> forward of the policy instance only -> tanh / noise / scale / clamp.
 extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows,

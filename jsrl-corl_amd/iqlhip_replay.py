@@ -184,13 +184,35 @@ class ReplayBuffer:
                        done: bool):
         # one packed host row, one H2D copy (the reference issues five, iql.py:189-193)
         S, A = self._state_dim, self._action_dim
-        row = np.zeros((self._ld,), dtype=np.float32)
+        if self._gpu:
+            # pinned staging rows (ring of 4, each guarded by an event) and an asynchronous copy
+            ring = getattr(self, "_row_ring", None)
+            if ring is None:
+                ring = [(torch.zeros(self._ld, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+                self._row_ring, self._row_slot = ring, 0
+            host, done_ev = ring[self._row_slot]
+            self._row_slot = (self._row_slot + 1) % len(ring)
+            done_ev.synchronize()
+            row = host.numpy()
+        else:
+            host = None
+            row = np.zeros((self._ld,), dtype=np.float32)
         row[:S] = np.asarray(state, dtype=np.float32).reshape(-1)
         row[S: S + A] = np.asarray(action, dtype=np.float32).reshape(-1)
         row[S + A: 2 * S + A] = np.asarray(next_state, dtype=np.float32).reshape(-1)
         row[2 * S + A] = np.float32(reward)
         row[2 * S + A + 1] = np.float32(done)
-        self._rows[self._pointer].copy_(torch.from_numpy(row))
+        if host is not None:
+            dev = self._rows.device
+            if torch.cuda.current_device() == dev.index:
+                self._rows[self._pointer].copy_(host, non_blocking=True)
+                done_ev.record()
+            else:
+                with torch.cuda.device(dev):
+                    self._rows[self._pointer].copy_(host, non_blocking=True)
+                    done_ev.record()
+        else:
+            self._rows[self._pointer].copy_(torch.from_numpy(row))
         self._pointer = (self._pointer + 1) % self._buffer_size
         self._size = min(self._size + 1, self._buffer_size)
 
