@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Stage-by-stage comparison of the HIP step against the oracle on the GPU box.
 Prints the max error of every intermediate so a wrong kernel stage is visible
-in one run.  Usage: python tools/gpu_diag.py [case ...]"""
+in one run (test infrastructure: it uses the oracle, so it lives under tests/).
+Usage: python tests/gpu_diag.py [case ...]"""
 import os
 import sys
 
