@@ -927,15 +927,28 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         av[ks][1] = (hh[ks][1] > 0.f) ? a1 * dscale : 0.f;
       }
     } else {
+      // wider heads: the same, 8 dims at a time (the dims of a started chunk are always written, zero beyond D)
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) { av[ks][0] = 0.f; av[ks][1] = 0.f; }
-      for (int dd = 0; dd < D; ++dd) {
-        const float wa = W2s[dd * 32 + 2 * l15], wb = W2s[dd * 32 + 2 * l15 + 1];
+      for (int d0 = 0; d0 < D; d0 += 8) {
+        float wa8[8], wb8[8];
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd) {
+          const f32x2 w = *(const f32x2*)(W2s + min(d0 + dd, D - 1) * 32 + 2 * l15);
+          wa8[dd] = (d0 + dd < D) ? w[0] : 0.f;
+          wb8[dd] = (d0 + dd < D) ? w[1] : 0.f;
+        }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          const float dy = dYs[(rbase + ks) * DYA + dd];
-          av[ks][0] = fmaf(dy, wa, av[ks][0]);
-          av[ks][1] = fmaf(dy, wb, av[ks][1]);
+          const f32x4 y0 = *(const f32x4*)(dYs + (rbase + ks) * DYA + d0);
+          const f32x4 y1 = *(const f32x4*)(dYs + (rbase + ks) * DYA + d0 + 4);
+          float a0 = av[ks][0], a1 = av[ks][1];
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) { a0 = fmaf(y0[dd], wa8[dd], a0); a1 = fmaf(y0[dd], wb8[dd], a1); }
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) { a0 = fmaf(y1[dd], wa8[4 + dd], a0); a1 = fmaf(y1[dd], wb8[4 + dd], a1); }
+          av[ks][0] = a0;
+          av[ks][1] = a1;
         }
       }
 #pragma unroll
@@ -1198,43 +1211,66 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     STAMP(p, 5);
 
     // dH1s[r][j] = (sum_dd dY[r][dd] W2[dd][j]) * (H1[r][j] > 0)
+    if (D > 8) {
+      // wide heads (policy with more than 8 action dims): 8 dims at a time, the chunk's 8 W2 rows loaded ONCE (the
+      // next chunk's while this one is multiplied) and used for all 8 rows of the thread; dY rows are zero-filled
+      // to Dp, so rows >= D of a chunk (clamped duplicates) add exact zeros — same sums, same order as per-row code
+      f32x4 sacc[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int rl = (tid + 256 * q) >> 6;
-      f32x4 s;
-      if (D == 1) {
-        s = dYs[rl * DYLD] * w2v;
-      } else if (D <= 8) {
-        // dYs is zero-filled up to Dp >= 8 and w2v8[j >= D] repeats row D-1: 8 unconditional LDS reads in one
-        // batch (a per-dim `if` makes each read -> wait -> fma a serial ~160-cycle step)
-        const f32x4 ya = *(const f32x4*)(dYs + rl * DYLD), yb = *(const f32x4*)(dYs + rl * DYLD + 4);
-        s = ya[0] * w2v8[0];
+      for (int q = 0; q < 8; ++q) sacc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 wv[8], wn[8];
 #pragma unroll
-        for (int j = 1; j < 4; ++j) s += ya[j] * w2v8[j];
+      for (int j = 0; j < 8; ++j) wv[j] = w2v8[j];
+      for (int d0 = 0; d0 < D; d0 += 8) {
+        const bool more = (d0 + 8 < D);
+        if (more) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += yb[j] * w2v8[4 + j];
-      } else {
-        s = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int d0 = 0; d0 < D; d0 += 8) {
-          f32x4 wv[8];
-          if (d0 == 0) {
+          for (int j = 0; j < 8; ++j) wn[j] = *(const f32x4*)(w2 + min(d0 + 8 + j, D - 1) * HID + 4 * j4);
+        }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wv[j] = w2v8[j];
-          } else {
+        for (int q = 0; q < 8; ++q) {
+          const int rl = (tid + 256 * q) >> 6;
+          const f32x4 ya = *(const f32x4*)(dYs + rl * DYLD + d0), yb = *(const f32x4*)(dYs + rl * DYLD + d0 + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wv[j] = *(const f32x4*)(w2 + min(d0 + j, D - 1) * HID + 4 * j4);
-          }
+          for (int j = 0; j < 4; ++j) sacc[q] += ya[j] * wv[j];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float dy = (d0 + j < D) ? dYs[rl * DYLD + min(d0 + j, D - 1)] : 0.f;
-            s += dy * wv[j];
-          }
+          for (int j = 0; j < 4; ++j) sacc[q] += yb[j] * wv[4 + j];
+        }
+        if (more) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wv[j] = wn[j];
         }
       }
-      f32x4 out;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
-      *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+      for (int q = 0; q < 8; ++q) {
+        const int rl = (tid + 256 * q) >> 6;
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? sacc[q][e] * dscale : 0.f;
+        *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int rl = (tid + 256 * q) >> 6;
+        f32x4 s;
+        if (D == 1) {
+          s = dYs[rl * DYLD] * w2v;
+        } else {
+          // dYs is zero-filled up to Dp >= 8 and w2v8[j >= D] repeats row D-1: unconditional float4 LDS reads in one
+          // batch (a per-dim `if` makes each read -> wait -> fma a serial ~160-cycle step)
+          const f32x4 ya = *(const f32x4*)(dYs + rl * DYLD), yb = *(const f32x4*)(dYs + rl * DYLD + 4);
+          s = ya[0] * w2v8[0];
+#pragma unroll
+          for (int j = 1; j < 4; ++j) s += ya[j] * w2v8[j];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s += yb[j] * w2v8[4 + j];
+        }
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
+        *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+      }
     }
     __syncthreads();
     STAMP(p, 6);
