@@ -662,6 +662,25 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /*>=4 floats*
 // Backward.  blockIdx & 7 = x: net = x & 3, half = x >> 2 (two XCD groups per net).
 // Within a net, local id < 32*n_chunk  -> (a) block: chunk c, j-tile jt (32 rows of W1), i-tile it (64 cols)
 //               otherwise              -> (b) block: row tile rt (32 rows), i-slice is (64 cols)
+// dH1pre tiles of one wave's 64 rows: pre[t][ta] += dY[16t.., 4 k1 + g] x W2s[4 k1 + g][2 l15 + ta], NK k-steps
+// (straight-line: all LDS operands of a k-step in one batch).
+template <int NK>
+__device__ __forceinline__ void dh1_mfma(f32x4 (&pre)[4][2], const float* dYs, const float* W2s, int DYA, int wave,
+                                         int g, int l15) {
+#pragma unroll
+  for (int k1 = 0; k1 < NK; ++k1) {
+    float a1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = dYs[(64 * wave + 16 * t + l15) * DYA + 4 * k1 + g];
+    const f32x2 b1 = *(const f32x2*)(W2s + (4 * k1 + g) * 32 + 2 * l15);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      pre[t][0] = MFMA16(a1[t], b1[0], pre[t][0]);
+      pre[t][1] = MFMA16(a1[t], b1[1], pre[t][1]);
+    }
+  }
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk, int n_rt) {
   RT_ENTRY();
@@ -757,13 +776,16 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       const int ec = min(tid + 256 * q, D * 32 - 1);      // clamped: unconditional load
       w2pre[q] = w2[(ec >> 5) * HID + j0 + (ec & 31)];
     }
-    // wave w reduces rows cbase + 64w + 16g + ks (ks = 0..15); rows >= B are clamped to a valid row:
-    // their dY is 0, so they contribute nothing.
+    // wave w reduces its 64 rows, 4 per MFMA: instruction ks of lane group g takes row AROW(ks) = 64w + 16(ks>>2) +
+    // 4g + (ks&3) — the row a lane's accumulator register (ks&3) of the 16-row tile (ks>>2) holds when dH1 itself
+    // comes out of an MFMA (wide heads, below), so that result feeds the dW1 MFMA without a shuffle.  Rows >= B are
+    // clamped to a valid row: their dY is 0, so they contribute nothing.
+#define AROW(ks) (64 * wave + 16 * ((ks) >> 2) + 4 * g + ((ks) & 3))
     f32x2 hh[16];
     f32x4 bb[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const int row = min(cbase + 64 * wave + 16 * g + ks, B - 1);
+      const int row = min(cbase + AROW(ks), B - 1);
       hh[ks] = *(const f32x2*)(H1g + row * HID + j0 + 2 * l15);
       bb[ks] = *(const f32x4*)(H0g + row * HID + i0 + 4 * l15);
     }
@@ -772,9 +794,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     {
       const int row = prow;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) {           // [Dp][32], zero rows beyond D (operand of the dH1 MFMA)
         const int e = tid + 256 * q;
-        if (e < D * 32) W2s[e] = w2pre[q];
+        if (e < Dp * 32) W2s[e] = (e < D * 32) ? w2pre[q] : 0.f;
       }
       float lossA = 0.f, lossB = 0.f;
       const PiConst pc = pi_consts(p, net, lsr);
@@ -799,13 +821,11 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         const float invB = p.inv_batch;
         for (int e = 0; 8 * e < Dp; ++e) {
           const int dd = sub + 8 * e;
-          if (8 * e >= A) {                    // padding dims up to Dp: zeros, no loads; only the dW2 MFMA of
-            if (do_dw2 || want_dls) {          // the block that forms dW2 (and the dlog_std sums) reads them
+          if (8 * e >= A) {                    // padding dims up to Dp (MFMA operands): zeros, no loads
 #pragma unroll
-              for (int cc = 0; cc < 8; ++cc) {
-                dYs[(r8 + 32 * cc) * DYA + dd] = 0.f;
-                if (want_dls) dLs[(r8 + 32 * cc) * DYA + dd] = 0.f;
-              }
+            for (int cc = 0; cc < 8; ++cc) {
+              dYs[(r8 + 32 * cc) * DYA + dd] = 0.f;
+              if (want_dls) dLs[(r8 + 32 * cc) * DYA + dd] = 0.f;
             }
             continue;
           }
@@ -890,12 +910,11 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     float av[16][2];
     float db1a[2] = {0.f, 0.f};
     float dw2a[2] = {0.f, 0.f};    // D == 1
-    const int rbase = 64 * wave + 16 * g;
     if (D == 1) {
       const float w2a = W2s[2 * l15], w2b = W2s[2 * l15 + 1];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        const float dy = dYs[(rbase + ks) * DYA];
+        const float dy = dYs[AROW(ks) * DYA];
         av[ks][0] = (hh[ks][0] > 0.f) ? dy * w2a * dscale : 0.f;
         av[ks][1] = (hh[ks][1] > 0.f) ? dy * w2b * dscale : 0.f;
         if (do_dw2) {
@@ -903,58 +922,21 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           dw2a[1] = fmaf(dy, hh[ks][1], dw2a[1]);
         }
       }
-    } else if (D <= 8) {
-      // the common policy widths: the 8 (zero-padded) dY of a row as two float4 LDS reads and the head weights of
-      // this lane's two j in registers — straight-line code instead of a D-trip loop of 18 scalar LDS reads each.
-      // Same fma order as the loop below (padding terms add exact zeros), so the results are bitwise the same.
-      float wa8[8], wb8[8];
-#pragma unroll
-      for (int dd = 0; dd < 8; ++dd) {
-        const f32x2 w = *(const f32x2*)(W2s + min(dd, D - 1) * 32 + 2 * l15);
-        wa8[dd] = (dd < D) ? w[0] : 0.f;
-        wb8[dd] = (dd < D) ? w[1] : 0.f;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const f32x4 y0 = *(const f32x4*)(dYs + (rbase + ks) * DYA);
-        const f32x4 y1 = *(const f32x4*)(dYs + (rbase + ks) * DYA + 4);
-        float a0 = y0[0] * wa8[0], a1 = y0[0] * wb8[0];
-#pragma unroll
-        for (int dd = 1; dd < 4; ++dd) { a0 = fmaf(y0[dd], wa8[dd], a0); a1 = fmaf(y0[dd], wb8[dd], a1); }
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) { a0 = fmaf(y1[dd], wa8[4 + dd], a0); a1 = fmaf(y1[dd], wb8[4 + dd], a1); }
-        av[ks][0] = (hh[ks][0] > 0.f) ? a0 * dscale : 0.f;
-        av[ks][1] = (hh[ks][1] > 0.f) ? a1 * dscale : 0.f;
-      }
     } else {
-      // wider heads: the same, 8 dims at a time (the dims of a started chunk are always written, zero beyond D)
+      // wide heads (policy): dH1pre[row][j] = sum_dd dY[row][dd] W2[dd][j] on the matrix cores — per wave 4 row
+      // tiles x 2 j tiles x Dp/4 k-steps (32 or 64 MFMAs) instead of 2 D fmas per (row, j) on the vector ALU (1 024
+      // per thread at D = 28).  A = dY (m = row 16t + l15, k = dd), B = W2 (k = dd, n = j = 2 l15 + ta, zero rows
+      // beyond D); lane (g, l15) gets rows 16t + 4g + reg = AROW(4t + reg): its own operand rows of the dW1 MFMA.
+      // fp32 MFMA is an exact fma chain over k, i.e. the same sum in the same dim order as the scalar code.
+      f32x4 pre[4][2];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) { av[ks][0] = 0.f; av[ks][1] = 0.f; }
-      for (int d0 = 0; d0 < D; d0 += 8) {
-        float wa8[8], wb8[8];
-#pragma unroll
-        for (int dd = 0; dd < 8; ++dd) {
-          const f32x2 w = *(const f32x2*)(W2s + min(d0 + dd, D - 1) * 32 + 2 * l15);
-          wa8[dd] = (d0 + dd < D) ? w[0] : 0.f;
-          wb8[dd] = (d0 + dd < D) ? w[1] : 0.f;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const f32x4 y0 = *(const f32x4*)(dYs + (rbase + ks) * DYA + d0);
-          const f32x4 y1 = *(const f32x4*)(dYs + (rbase + ks) * DYA + d0 + 4);
-          float a0 = av[ks][0], a1 = av[ks][1];
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) { a0 = fmaf(y0[dd], wa8[dd], a0); a1 = fmaf(y0[dd], wb8[dd], a1); }
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) { a0 = fmaf(y1[dd], wa8[4 + dd], a0); a1 = fmaf(y1[dd], wb8[4 + dd], a1); }
-          av[ks][0] = a0;
-          av[ks][1] = a1;
-        }
-      }
+      for (int t = 0; t < 4; ++t) { pre[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; pre[t][1] = pre[t][0]; }
+      if (Dp == 16) dh1_mfma<4>(pre, dYs, W2s, DYA, wave, g, l15);
+      else dh1_mfma<8>(pre, dYs, W2s, DYA, wave, g, l15);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        av[ks][0] = (hh[ks][0] > 0.f) ? av[ks][0] * dscale : 0.f;
-        av[ks][1] = (hh[ks][1] > 0.f) ? av[ks][1] * dscale : 0.f;
+        av[ks][0] = (hh[ks][0] > 0.f) ? pre[ks >> 2][0][ks & 3] * dscale : 0.f;
+        av[ks][1] = (hh[ks][1] > 0.f) ? pre[ks >> 2][1][ks & 3] * dscale : 0.f;
       }
     }
     if (do_db1) {
@@ -1011,7 +993,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       // 16 exposed LDS latencies made these blocks the last of the kernel)
       float ad[16];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[(rbase + ks) * DYA + l15];
+      for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[AROW(ks) * DYA + l15];
       float hsel[16];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) hsel[ks] = tb_own ? hh[ks][1] : hh[ks][0];
@@ -1019,7 +1001,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int ks = 0; ks < 16; ++ks) acc2[0][0] = MFMA16(ad[ks], hsel[ks], acc2[0][0]);
       if (ndt > 1) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[(rbase + ks) * DYA + 16 + l15];
+        for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[AROW(ks) * DYA + 16 + l15];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) acc2[1][0] = MFMA16(ad[ks], hsel[ks], acc2[1][0]);
       }
@@ -1092,6 +1074,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     RT_STAMP(p, 15, iql_realtime());
     return;
   }
+#undef AROW
 
   // ===================== (b): dH0 / dW0 / db0 for one 32-row tile and 64-column slice =====================
   {
