@@ -196,7 +196,7 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   const int kq = dims->state_dim + dims->action_dim;
   const int ks_ = dims->state_dim;   // V / pi layer-0 width; Q nets use kq
   const int w0_lds_k = (kq <= W0_LDS_MAX_K) ? kq : ((ks_ <= W0_LDS_MAX_K) ? ks_ : 0);
-  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * (int)c->row_ld + ((A * 65 + 3) & ~3) + 512 + 16 +
+  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * (int)c->row_ld + (((A + 15) & ~15) * W2_LD + 32) + 512 + 16 +
                         HID * w0_lds_k) * sizeof(float);
   // One block per CU while the grid fits the chip (co-resident blocks share a CU's L1 and fill rate and only slow
   // each other down); the exact size — two blocks per CU where it is <= 80 KB — once there are more blocks than CUs.

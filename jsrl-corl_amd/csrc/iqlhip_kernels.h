@@ -33,6 +33,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define NSPLIT 4            // column slices of the hidden layer per row tile
 #define HEAD_LD 24          // scalar head partials per row: [inst 0..5][ns 0..3]
 #define W0_LDS_MAX_K 64     // layer-0 weights are staged in LDS when k_in <= this (64 KiB)
+#define W2_LD 68            // row stride of the forward's head-weight tile in LDS (64 units + 4: bank spread)
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -251,8 +252,9 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   float* Xr = H1s + RT_ROWS * T64_LD;        // [32][ld]  packed rows of this tile
   // (regions sized by the ACTUAL dims, not the limits: at S=17/A=6 the block needs 75 KB instead of 109 KB, so two
   //  blocks fit a CU's 160 KB when a large batch brings more than one block per CU; host: fwd_lds_floats())
-  float* W2s = Xr + RT_ROWS * ld;            // [D][64] head weights of this column slice, then b2[D] (D <= A)
-  const int w2s_words = (Aact * 65 + 3) & ~3;
+  // [Dp][W2_LD] head weights of this column slice (rows beyond D zero: MFMA operand), then b2[D]; D <= A
+  float* W2s = Xr + RT_ROWS * ld;
+  const int w2s_words = ((Aact + 15) & ~15) * W2_LD + 32;
   unsigned* Mk = (unsigned*)(W2s + w2s_words);       // [2][32][8] dropout keep-bits of the tile
   float* W0s = W2s + w2s_words + 512;        // [256*k0] flat copy of layer-0 weights (when w0_lds); 16-B aligned
   // (no integer casts on LDS pointers: they would demote every access to a flat load, and a flat load
@@ -306,12 +308,13 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + n1 * HID + 16 * ks + 4 * g);
 
   xr_store(xr, Xr, n_x);
+  const int Dp = (D + 15) & ~15;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int e = tid + 256 * q;
-    if (e < D * 16) *(f32x4*)(W2s + 4 * e) = w2pre[q];
+    if (e < Dp * 16) *(f32x4*)(W2s + (e >> 4) * W2_LD + 4 * (e & 15)) = (e < D * 16) ? w2pre[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  if (tid < D) W2s[D * 64 + tid] = b2v;
+  if (tid < D) W2s[Dp * W2_LD + tid] = b2v;
   Mk[tid] = mk0;
   Mk[256 + tid] = mk1;
   if (w0_lds) {
@@ -526,42 +529,34 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       acc += __shfl_xor(acc, 1);
       acc += __shfl_xor(acc, 2);
       acc += __shfl_xor(acc, 4);
-      if (ns == 0) acc += W2s[64];
+      if (ns == 0) acc += W2s[Dp * W2_LD];
       if (sub == 0 && row < B) {
         if (inst < 6) headsg[row * HEAD_LD + inst * NSPLIT + ns] = acc;
         else headsg[MB * HEAD_LD + row * NSPLIT + ns] = acc;           // a policy with one action dim
       }
     } else {
-      // policy head: 8 action dims at a time as straight-line code — 8 independent read -> fma -> shuffle chains
-      // overlap (as a D-trip loop each dim was a serial ~500-cycle step and the policy instance the forward's
-      // long pole); after the reduction every lane of a row group holds all sums and lane `sub` stores dim d0 + sub.
-      // Per dim the arithmetic and its order are unchanged.
-      for (int d0 = 0; d0 < D; d0 += 8) {
-        float accs[8];
+      // policy head on the matrix cores: partial[32 rows][Dp] = H1s[32][64] x W2s^T — wave w takes row tile w & 1
+      // and the 16 action dims of tile w >> 1 (waves beyond Dp / 16 tiles idle), 16 dependent MFMAs over the block's
+      // 64 units.  A = H1 (m = row, k = unit), B = W2 (k = unit, n = dim, zero rows beyond D).  (As scalar code the
+      // policy instance was the forward's long pole: ~500 cycles per action dim.)
+      if (16 * (wave >> 1) < Dp) {
+        const int i = wave & 1, nt = wave >> 1;
+        float a[16], b[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float* w2r = W2s + min(d0 + j, D - 1) * 64;
-          const f32x4 wa = *(const f32x4*)(w2r + 4 * sub);
-          const f32x4 wb = *(const f32x4*)(w2r + 32 + 4 * sub);
-          float acc = 0.f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = fmaf(ha[e], wa[e], acc);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = fmaf(hb[e], wb[e], acc);
-          accs[j] = acc;
+        for (int ks = 0; ks < 16; ++ks) {
+          a[ks] = H1s[(16 * i + l15) * T64_LD + 4 * ks + g];
+          b[ks] = W2s[(16 * nt + l15) * W2_LD + 4 * ks + g];
         }
+        f32x4 hacc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          accs[j] += __shfl_xor(accs[j], 1);
-          accs[j] += __shfl_xor(accs[j], 2);
-          accs[j] += __shfl_xor(accs[j], 4);
+        for (int ks = 0; ks < 16; ++ks) hacc = MFMA16(a[ks], b[ks], hacc);
+        const int dd = 16 * nt + l15;
+        const float bias = (ns == 0) ? W2s[Dp * W2_LD + min(dd, D - 1)] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int prow_ = row0 + 16 * i + 4 * g + reg;
+          if (dd < D && prow_ < B) headsg[MB * HEAD_LD + (prow_ * Aact + dd) * NSPLIT + ns] = hacc[reg] + bias;
         }
-        float mine = accs[0];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) mine = (sub == j) ? accs[j] : mine;
-        const int dd = d0 + sub;
-        if (ns == 0) mine += W2s[D * 64 + min(dd, D - 1)];
-        if (dd < D && row < B) headsg[MB * HEAD_LD + (row * Aact + dd) * NSPLIT + ns] = mine;
       }
     }
   }
