@@ -74,6 +74,7 @@ struct iqlhip_ctx {
   int n_chunk_max = 0, n_rt_max = 0;
   size_t lds_fwd = 0, lds_fwd_solo = 0, lds_bwd = 0;
   int n_cus = 256;                    // compute units of the device (MI355X: 256)
+  int w0_lds_k = 0;                   // widest layer-0 input whose weights the forward stages in LDS
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
   hipStream_t cap_stream = nullptr;
   struct CachedGraph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; };
@@ -195,9 +196,17 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   // LDS sizes
   const int kq = dims->state_dim + dims->action_dim;
   const int ks_ = dims->state_dim;   // V / pi layer-0 width; Q nets use kq
-  const int w0_lds_k = (kq <= W0_LDS_MAX_K) ? kq : ((ks_ <= W0_LDS_MAX_K) ? ks_ : 0);
-  c->lds_fwd = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * (int)c->row_ld + (((A + 15) & ~15) * W2_LD + 32) + 512 + 16 +
-                        HID * w0_lds_k) * sizeof(float);
+  // layer-0 weights are staged in LDS for every instance whose input width fits: through registers up to
+  // W0_LDS_MAX_K, by LDS-DMA (no registers) above that, as far as the CU's 160 KB allow (1 KiB-float4 slack for the
+  // DMA's whole-wave granularity)
+  const size_t fwd_fixed = (size_t)(RT_ROWS * H0_LD + RT_ROWS * T64_LD + RT_ROWS * (int)c->row_ld +
+                                    (((A + 15) & ~15) * W2_LD + 32) + 512 + 16) * sizeof(float);
+  auto fits = [&](int k) { return fwd_fixed + (size_t)HID * k * sizeof(float) + 4096 <= (size_t)160 * 1024 - 1024; };
+  int w0_lds_k = 0;
+  if (kq <= W0_DMA_MAX_K && fits(kq)) w0_lds_k = kq;
+  else if (ks_ <= W0_DMA_MAX_K && fits(ks_)) w0_lds_k = ks_;
+  c->w0_lds_k = w0_lds_k;
+  c->lds_fwd = fwd_fixed + (size_t)HID * w0_lds_k * sizeof(float) + (w0_lds_k > W0_LDS_MAX_K ? 4096 : 0);
   // One block per CU while the grid fits the chip (co-resident blocks share a CU's L1 and fill rate and only slow
   // each other down); the exact size — two blocks per CU where it is <= 80 KB — once there are more blocks than CUs.
   c->lds_fwd_solo = std::max(c->lds_fwd, (size_t)(81 * 1024));
@@ -210,9 +219,11 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   const size_t lds_b = (size_t)(RT_ROWS * H0_LD + 4 * 32 * T64_LD + RT_ROWS * T64_LD + RT_ROWS * 36 + 4 +
                                 RT_ROWS * XR_LD_MAX) * sizeof(float);
   c->lds_bwd = std::max(lds_a, lds_b);
-  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
   HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
-  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
   HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
   *out = c;
   return IQLHIP_OK;
@@ -390,6 +401,7 @@ static StepParams make_step(const iqlhip_ctx* c, int rows, float inv_batch) {
   p.drop_bits = (c->drop_p > 0.f) ? c->drop_bits : nullptr;
   p.drop_scale = (c->drop_p > 0.f) ? 1.f / (1.f - c->drop_p) : 1.f;
   p.only_inst = -1;
+  p.w0_lds_k = c->w0_lds_k;
   p.g_rows = nullptr; p.g_ld = c->row_ld; p.g_idx = nullptr; p.g_xb = nullptr; p.g_n = 0;
   return p;
 }
@@ -420,11 +432,22 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
 
 static size_t fwd_lds(const iqlhip_ctx* c, int n_blocks) { return (n_blocks <= c->n_cus) ? c->lds_fwd_solo : c->lds_fwd; }
 
+static void launch_fwd_grid(const iqlhip_ctx* c, const StepParams& p, int nb, hipStream_t st) {
+  const bool dma = c->w0_lds_k > W0_LDS_MAX_K;       // some instance stages wide layer-0 weights by LDS-DMA
+  const size_t lds = fwd_lds(c, nb);
+  if (c->precision == 1) {
+    if (dma) hipLaunchKernelGGL((iql_fwd_kernel<true, true>), dim3(nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((iql_fwd_kernel<true, false>), dim3(nb), dim3(256), lds, st, p);
+  } else {
+    if (dma) hipLaunchKernelGGL((iql_fwd_kernel<false, true>), dim3(nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((iql_fwd_kernel<false, false>), dim3(nb), dim3(256), lds, st, p);
+  }
+}
+
 static void launch_fwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   const int nb = 8 * n_rt * NSPLIT;
-  if (c->precision == 1) hipLaunchKernelGGL(iql_fwd_kernel<true>, dim3(nb), dim3(256), fwd_lds(c, nb), st, p);
-  else hipLaunchKernelGGL(iql_fwd_kernel<false>, dim3(nb), dim3(256), fwd_lds(c, nb), st, p);
+  launch_fwd_grid(c, p, nb, st);
 }
 static void launch_bwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
@@ -740,8 +763,7 @@ extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int6
   p.sc.heads = c->heads_act; // the policy partials of row r land at heads[max_batch * HEAD_LD + r * A * NSPLIT ...]:
   p.sc.max_batch = 0;        // with max_batch = 0 that is heads_act[r * A * NSPLIT ...]
   const int n_rt = (rows + RT_ROWS - 1) / RT_ROWS;
-  if (c->precision == 1) hipLaunchKernelGGL(iql_fwd_kernel<true>, dim3(n_rt * NSPLIT), dim3(256), fwd_lds(c, n_rt * NSPLIT), st, p);
-  else hipLaunchKernelGGL(iql_fwd_kernel<false>, dim3(n_rt * NSPLIT), dim3(256), fwd_lds(c, n_rt * NSPLIT), st, p);
+  launch_fwd_grid(c, p, n_rt * NSPLIT, st);
   hipLaunchKernelGGL(iql_actor_finish_kernel, dim3((rows * A + 255) / 256), dim3(256), 0, st, c->heads_act, rows, A,
                      max_action, p.log_std, c->hyper.log_std_min, c->hyper.log_std_max, noise_dev, (long long)ld_noise,
                      actions_dev, (long long)ld_a);

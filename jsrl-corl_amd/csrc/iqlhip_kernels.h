@@ -32,7 +32,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define T64_LD 68           // LDS row stride of a [rows][64] tile
 #define NSPLIT 4            // column slices of the hidden layer per row tile
 #define HEAD_LD 24          // scalar head partials per row: [inst 0..5][ns 0..3]
-#define W0_LDS_MAX_K 64     // layer-0 weights are staged in LDS when k_in <= this (64 KiB)
+#define W0_LDS_MAX_K 64     // layer-0 weights are staged in LDS through registers when k_in <= this (64 KiB)
+#define W0_DMA_MAX_K 96     // ... and by LDS-DMA up to this width, LDS permitting (host: iqlhip_create)
 #define W2_LD 68            // row stride of the forward's head-weight tile in LDS (64 units + 4: bank spread)
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -142,6 +143,7 @@ struct StepParams {
   // >= 0: forward ONE instance only (grid = n_rt * NSPLIT, blockIdx = row tile * NSPLIT + column slice) — the
   // policy-inference entry point iqlhip_actor_forward; -1: the training forward over all 7 instances
   int only_inst;
+  int w0_lds_k;             // instances with k_in <= this stage their layer-0 weights in LDS
   // next step's batch (hipGraph chunks): the forward's idle blocks (blockIdx & 7 == 7, one per row tile and column
   // slice) copy rows[idx[r]] -> g_xb[r] (whole padded rows) into the OTHER staging buffer while the 7 instances run.
   // In the update kernel the two dependent HBM round trips (index, then row) stretched that kernel by ~0.8 us.
@@ -211,7 +213,10 @@ __device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld
 // Forward: block = (instance, row tile of 32 rows, column slice ns of 64 hidden-1 units).
 // grid = 8 * n_rt * NSPLIT; blockIdx & 7 = instance (7 = idle) so that the
 // blocks of one instance share an XCD and hence one L2 copy of its weights.
-template <bool BF16>
+// W0DMA: the variant that may stage wide layer-0 weights by LDS-DMA.  A separate instantiation because the mere
+// presence of an LDS-DMA makes the compiler wait vmcnt(0) before LDS reads on every path it may reach (measured:
+// +1 us on the narrow-input configs, whose W1 prefetch then no longer streams under layer 0).
+template <bool BF16, bool W0DMA>
 __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   RT_ENTRY();
   const int bid = blockIdx.x;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   const int D = np.d;
   const int ld = p.ld;
   const int B = p.rows;
-  const bool w0_lds = (k0 <= W0_LDS_MAX_K);
+  const int w0k = p.w0_lds_k;
   const float* xb = p.xb;
   float* h0g = p.sc.h0;
   float* h1g = p.sc.h1;
@@ -244,7 +249,9 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   const int Aact = p.A;
   PIN_P(np.w0); PIN_P(np.b0); PIN_P(np.w1); PIN_P(np.b1); PIN_P(np.w2); PIN_P(np.b2);
   PIN_S(k0); PIN_S(D); PIN_S(xoff); PIN_S(slot); PIN_S(ld); PIN_S(B); PIN_S(MB); PIN_S(Aact);
-  PIN_P(xb); PIN_P(h0g); PIN_P(h1g); PIN_P(headsg);
+  PIN_P(xb); PIN_P(h0g); PIN_P(h1g); PIN_P(headsg); PIN_S(w0k);
+  const bool w0_lds = W0DMA ? (k0 <= w0k) : (k0 <= min(w0k, W0_LDS_MAX_K));
+  const bool w0_dma = W0DMA && w0_lds && (k0 > W0_LDS_MAX_K);      // wide inputs: copied by LDS-DMA, no staging registers
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* H0s = smem;                         // [32][H0_LD]
@@ -293,7 +300,14 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   // (c) layer-0 weights: flat float4 copy of 64*k0 float4 (thread handles tid + 256 j); 8 loads cover k0 <= 32
   const int n_w0v = 64 * k0;
   f32x4 w0v[16];
-  if (w0_lds) {
+  if (w0_dma) {
+    // whole waves of 64 x 16 B: global (per-lane address, clamped) -> LDS (wave base + lane * 16); the tail wave
+    // writes into the region's 4 KiB slack.  The barrier below then waits for every outstanding load (the DMA is
+    // tracked by vmcnt), so on this path the W1 fragments are requested after it and stream in under layer 0.
+    const int nj = (n_w0v + 255) >> 8;
+    for (int j = 0; j < nj; ++j)
+      lds_dma16(np.w0 + 4 * min(tid + 256 * j, n_w0v - 1), W0s + 4 * (256 * j + 64 * wave));
+  } else if (w0_lds) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) w0v[j] = *(const f32x4*)(np.w0 + 4 * min(tid + 256 * j, n_w0v - 1));
     if (k0 > 32) {
@@ -304,8 +318,10 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   // (d) this wave's W1 rows (16 output units x 256 k) as MFMA fragments: 64 KiB per block
   const int n1 = ns * 64 + wave * 16 + l15;  // hidden-1 unit of this lane
   f32x4 bw[16];
+  if (!w0_dma) {
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + n1 * HID + 16 * ks + 4 * g);
+    for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + n1 * HID + 16 * ks + 4 * g);
+  }
 
   xr_store(xr, Xr, n_x);
   const int Dp = (D + 15) & ~15;
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   if (tid < D) W2s[Dp * W2_LD + tid] = b2v;
   Mk[tid] = mk0;
   Mk[256 + tid] = mk1;
-  if (w0_lds) {
+  if (w0_lds && !w0_dma) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int f = tid + 256 * j;
@@ -332,6 +348,10 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     }
   }
   __syncthreads();
+  if (w0_dma) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + n1 * HID + 16 * ks + 4 * g);
+  }
   STAMP(p, 1);
 
   // ---- layer 0: this wave computes H0[32][64*wave .. +64).  Operand roles: A = W0 (m = hidden unit),
