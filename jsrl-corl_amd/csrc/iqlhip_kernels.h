@@ -898,8 +898,37 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     }
     __syncthreads();
     STAMP(p, 1);
-    if (designated) {
-      // db2[dd] = sum_r dY[r][dd];  dlog_std[dd] = sum_r w (1 - diff^2/var) * inv_batch (inside clamp range only)
+    if (designated && D > 8) {
+      // db2[dd] = sum_r dY[r][dd];  dlog_std[dd] = sum_r w (1 - diff^2/var) * inv_batch (inside clamp range only).
+      // Wide heads: thread (dim tid & 31, row group tid >> 5) sums 32 rows, the 8 partial sums meet in LDS (the
+      // tile-reduction buffer is idle until after the MFMA phase; only wave 0's part of it is touched here).  A
+      // dim per wave and iteration, each with its own load and store, took ~1.4 k cycles per dim: 9.7 k at D = 28
+      // (for D <= 8 that loop, at most two dims per wave, is the cheaper one and stays).
+      const bool gls = (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN);
+      const int dd = tid & 31, rg = tid >> 5;
+      float s = 0.f, sl = 0.f;
+      if (dd < D) {
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+          s += dYs[(rg * 32 + r) * DYA + dd];
+          if (gls) sl += dLs[(rg * 32 + r) * DYA + dd];
+        }
+      }
+      red[rg * 64 + dd] = s;
+      red[rg * 64 + 32 + dd] = sl;
+      __syncthreads();                 // (block-uniform condition)
+      if (tid < D) {
+        float ts = 0.f, tl = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ts += red[k * 64 + tid]; tl += red[k * 64 + 32 + tid]; }
+        slab[go.b2 + tid] = ts;
+        if (gls) {
+          const float lsr = p.log_std[tid];
+          const bool inside = (lsr >= p.hy.log_std_min) && (lsr <= p.hy.log_std_max);
+          slab[go.log_std + tid] = inside ? tl * p.inv_batch : 0.f;
+        }
+      }
+    } else if (designated) {
       for (int dd = wave; dd < D; dd += 4) {
         float s = 0.f, sl = 0.f;
 #pragma unroll
