@@ -185,6 +185,10 @@ int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t state_dim, int
  * strides = iqlhip_row_stride, 16-byte aligned) is consumed IN PLACE by iqlhip_step / iqlhip_forward_backward. */
 int iqlhip_rows_gather_packed(const float* rows_dev, int64_t ld, const int64_t* idx_dev, int64_t n,
                               float* out_rows_dev, void* stream);
+/* ... with the indices still in (pinned) host memory, as np.random.randint leaves them (iql.py:172): copies them to
+ * idx_scratch_dev on `stream`, then gathers.  idx_host must stay untouched until that copy has run. */
+int iqlhip_rows_gather_packed_h(const float* rows_dev, int64_t ld, const int64_t* idx_host, int64_t* idx_scratch_dev,
+                                int64_t n, float* out_rows_dev, void* stream);
 /* Device-side index draw used by iqlhip_train_steps, exposed for tests. */
 int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed, uint64_t offset, void* stream);
 

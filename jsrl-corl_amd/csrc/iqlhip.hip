@@ -740,6 +740,17 @@ extern "C" int iqlhip_stream_synchronize(void* stream) {
   return IQLHIP_OK;
 }
 
+// The same with the indices still on the host (pinned): one H2D copy into idx_scratch_dev, then the gather —
+// ReplayBuffer.sample's whole device side in one call.
+extern "C" int iqlhip_rows_gather_packed_h(const float* rows_dev, int64_t ld, const int64_t* idx_host,
+                                           int64_t* idx_scratch_dev, int64_t n, float* out_rows_dev, void* stream) {
+  if (!idx_host || !idx_scratch_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (n < 0) return fail(IQLHIP_EINVAL, "bad rows_gather_packed_h geometry");
+  if (n == 0) return IQLHIP_OK;
+  HIPCHK(hipMemcpyAsync(idx_scratch_dev, idx_host, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+  return iqlhip_rows_gather_packed(rows_dev, ld, idx_scratch_dev, n, out_rows_dev, stream);
+}
+
 // ---------------------------------------------------------------------------
 // Policy inference: pack states -> forward of the policy instance only -> tanh / noise / scale / clamp.
 extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows,
