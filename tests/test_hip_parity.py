@@ -649,3 +649,35 @@ def test_online_loop_body_runs_on_the_device_and_keeps_ring_semantics():
         s_, a_, r_, ns_, d_ = added[k]
         want = np.concatenate([s_, a_, ns_, [r_, d_]])
         assert np.array_equal(rows[i, : 2 * S + A + 2], want), i
+
+
+def test_thousand_step_run_tracks_the_cpu_port_statistically():
+    """BASELINE configs[0] flavour (offline loop, halfcheetah dims, batch 256, 1 k steps) on synthetic data: beyond
+    ~50 steps two fp32 trajectories diverge chaotically even for the reference against itself, so the
+    library's 1 000-step run (device indices, hipGraph chunks) is compared with the PyTorch-CPU port of the reference
+    step (numpy indices) on the statistics of the loss curves: window means of all three losses within 10 %."""
+    import iql
+    from hip_helpers import build_hip_trainer
+    from oracle.iql_torch_port import CpuIQL
+    S, A, N, B, K = 17, 6, 20000, 256, 1000
+    data = synth.synth_transitions(N, S, A, seed=31)
+    params = synth.synth_params(S, A, seed=32, perturb_target=False)
+    buf = iql.OfflineReplayBuffer(S, A, N, "cuda")
+    buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    tr = build_hip_trainer(params, S, A, True, _HYPER, _LRS, K)
+    got = tr.train_steps(buf, K, B, seed=3)                       # [K, 3]
+    torch.set_num_threads(4)
+    cpu = CpuIQL(S, A, params, gaussian=True, max_steps=K)
+    rng = np.random.default_rng(3)
+    want = np.zeros((K, 3))
+    for k in range(K):
+        idx = rng.integers(0, N, size=B)
+        tb = [torch.from_numpy(data["observations"][idx]), torch.from_numpy(data["actions"][idx]),
+              torch.from_numpy(data["rewards"][idx][:, None]), torch.from_numpy(data["next_observations"][idx]),
+              torch.from_numpy(data["terminals"][idx][:, None])]
+        log = cpu.train(tb)
+        want[k] = [log["value_loss"], log["q_loss"], log["actor_loss"]]
+    assert np.all(np.isfinite(got))
+    for lo, hi in ((0, 100), (400, 600), (800, 1000)):
+        g, w = got[lo:hi].mean(0), want[lo:hi].mean(0)
+        assert np.all(np.abs(g - w) <= 0.10 * np.abs(w) + 1e-3), (lo, hi, g, w)
