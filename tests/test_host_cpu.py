@@ -65,6 +65,26 @@ def test_error_codes_map_to_reference_exception_types():
         hb.arena_layout(0, 6, True)
 
 
+def test_argument_validation_precedes_any_device_work():
+    """Entry points reject bad arguments before touching the GPU (so these run on a CPU-only host)."""
+    lib = hb.lib()
+    # NULL pointers / bad geometry -> IQLHIP_EINVAL -> ValueError
+    for call in (
+        lambda: lib.iqlhip_rows_gather_packed(None, 44, None, 4, None, None),
+        lambda: lib.iqlhip_rows_gather_packed(16, 43, 16, 4, 16, None),           # stride not a multiple of 4 floats
+        lambda: lib.iqlhip_rows_gather_packed(8, 44, 16, 4, 16, None),            # rows not 16-byte aligned
+        lambda: lib.iqlhip_rows_gather_packed_h(16, 44, None, None, 4, 16, None),
+        lambda: lib.iqlhip_actor_forward(None, None, 17, 1, None, 6, 1.0, None, 6, None),
+        lambda: lib.iqlhip_rows_gather(None, 44, 17, 6, None, 4, None, None, None, None, None, None),
+        lambda: lib.iqlhip_draw_indices(None, 4, 10, 0, 0, None),
+    ):
+        with pytest.raises(ValueError):
+            hb.check(call())
+    assert "argument" in hb.last_error().lower() or hb.last_error()
+    # zero rows are a no-op, not an error
+    hb.check(lib.iqlhip_rows_gather_packed(16, 44, 16, 0, 16, None))
+
+
 # ---------------------------------------------------------------- replay buffer host logic
 def test_replay_buffer_sample_matches_reference_fixture():
     z, meta = load_golden("g3_gather")
