@@ -112,19 +112,29 @@ def eval_actor(env, actor: nn.Module, device: str, n_episodes: int, seed: int) -
 
 
 def return_reward_range(dataset: Dict, max_episode_steps: int) -> Tuple[float, float]:
-    """min / max episode return of a D4RL dataset (iql.py:262-274), vectorised:
-    an episode ends at a terminal or after max_episode_steps steps."""
-    rewards = np.asarray(dataset["rewards"], dtype=np.float64)
-    terminals = np.asarray(dataset["terminals"]).astype(bool)
-    returns = []
-    ep_ret, ep_len = 0.0, 0
-    for r, d in zip(rewards.tolist(), terminals.tolist()):
-        ep_ret += r
-        ep_len += 1
-        if d or ep_len == max_episode_steps:
-            returns.append(ep_ret)
-            ep_ret, ep_len = 0.0, 0
-    return min(returns), max(returns)
+    """min / max episode return of a D4RL dataset (semantics of iql.py:262-274): an episode ends at a terminal
+    flag or after max_episode_steps steps, whichever comes first; a trailing unfinished episode is not counted.
+    Episode boundaries are found per terminal-delimited run (a 1 M-row locomotion dataset has ~1 k of them), the
+    returns with one segmented float64 sum — no per-transition Python loop."""
+    rewards = np.asarray(dataset["rewards"], dtype=np.float64).reshape(-1)
+    n = rewards.shape[0]
+    term_at = np.flatnonzero(np.asarray(dataset["terminals"]).reshape(-1).astype(bool))
+    run_first = np.concatenate(([0], term_at + 1))
+    run_stop = np.concatenate((term_at + 1, [n]))                  # exclusive
+    pieces = []
+    for i, (lo, hi) in enumerate(zip(run_first.tolist(), run_stop.tolist())):
+        if hi <= lo:
+            continue
+        cuts = np.arange(lo + max_episode_steps - 1, hi, max_episode_steps)      # time-limit ends inside the run
+        if i < term_at.shape[0] and (cuts.size == 0 or cuts[-1] != hi - 1):
+            cuts = np.append(cuts, hi - 1)                                        # the run's terminal step
+        pieces.append(cuts)
+    last = np.concatenate(pieces) if pieces else np.zeros(0, dtype=np.int64)
+    if last.size == 0:
+        raise ValueError("min() arg is an empty sequence")        # what the reference's min(returns) raises
+    first = np.concatenate(([0], last[:-1] + 1))
+    returns = np.add.reduceat(np.append(rewards, 0.0), np.append(first, last[-1] + 1))[:-1]
+    return float(returns.min()), float(returns.max())
 
 
 def modify_reward(dataset: Dict, env_name: str, max_episode_steps: int = 1000) -> Dict:

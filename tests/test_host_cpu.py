@@ -251,3 +251,30 @@ def test_host_helpers():
     m, s = iql.compute_mean_std(np.array([[0.0, 2.0], [2.0, 2.0]]), 1e-3)
     assert np.allclose(m, [1.0, 2.0]) and np.allclose(s, [1.001, 0.001])
     assert iql.is_goal_reached(0.0, {"success": True}) and not iql.is_goal_reached(0.0, {})
+
+
+def test_return_reward_range_equals_the_sequential_definition():
+    """iql.py:262-274 walks the dataset transition by transition; the build finds the episode ends per
+    terminal-delimited run.  Same episodes, same returns, on random terminal / time-limit patterns — including the
+    reference's ValueError when no episode ever ends."""
+    def sequential(rew, term, limit):
+        out, acc, steps = [], 0.0, 0
+        for r, d in zip(rew.tolist(), term.tolist()):
+            acc, steps = acc + r, steps + 1
+            if d or steps == limit:
+                out.append(acc)
+                acc, steps = 0.0, 0
+        return (min(out), max(out)) if out else None
+
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n, limit = int(rng.integers(1, 300)), int(rng.integers(1, 12))
+        ds = {"rewards": rng.standard_normal(n).astype(np.float32),
+              "terminals": rng.random(n) < rng.choice([0.0, 0.02, 0.3, 1.0])}
+        want = sequential(ds["rewards"], ds["terminals"], limit)
+        if want is None:
+            with pytest.raises(ValueError):
+                iql.return_reward_range(ds, limit)
+        else:
+            got = iql.return_reward_range(ds, limit)
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
