@@ -412,6 +412,11 @@ def test_bf16_large_batch_config5_shape():
     (17, 6, 1, True),        # single row
     (17, 6, 257, True),      # one row past a 256-row chunk
     (50, 10, 300, True),     # k_in = 60 (V: 50): LDS-staged W0 through the generic k loop
+    (65, 31, 70, True),      # k_in = 96: the widest layer-0 copy by LDS-DMA; 31 action dims (ragged last chunk of 8)
+    (64, 32, 256, False),    # k_in = 96 and action_dim = 32 together, deterministic policy
+    (40, 17, 256, True),     # 17 action dims: Dp = 32 with 15 padding dims; Q inputs 57 wide (register-staged)
+    (3, 9, 33, True),        # 9 action dims: second 8-dim group holds a single dim
+    (39, 28, 1024, True),    # config 5 per-GPU shape: 4 chunks, 32 row tiles
 ])
 def test_edge_shapes_match_oracle(S, A, B, gaussian):
     from oracle import iql_oracle as O
