@@ -204,6 +204,11 @@ int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed
 int iqlhip_actor_forward(iqlhip_ctx* ctx, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
                          int64_t ld_noise, float max_action, float* actions_dev, int64_t ld_a, void* stream);
 
+/* The training-mode act() of a Gaussian policy with the N(0,1) draw of dist.sample() (iql.py:376) made on the device
+ * (Philox4x32-10 keyed by `seed` != 0, counter = (element, call number kept by the context), Box-Muller). */
+int iqlhip_actor_sample(iqlhip_ctx* ctx, const float* states_dev, int64_t ld_s, int32_t rows, uint64_t seed,
+                        float max_action, float* actions_dev, int64_t ld_a, void* stream);
+
 /* Block the host until everything queued on `stream` has finished (hipStreamSynchronize): the completion point of
  * iqlhip_actor_forward when its buffers are host-mapped, i.e. the `.cpu()` of the reference's act() (iql.py:379). */
 int iqlhip_stream_synchronize(void* stream);

@@ -57,6 +57,7 @@ struct iqlhip_ctx {
   float* heads_act = nullptr;         // [act_cap][A][NSPLIT]
   float* losses_host = nullptr;       // pinned landing pad of read_losses (a pageable D2H goes through a bounce copy)
   int act_cap = 0;
+  unsigned long long act_calls = 0;   // Philox call counter of iqlhip_actor_sample
   int64_t row_ld = 0;
   // actor dropout
   unsigned* drop_bits = nullptr;      // [2][max_batch][8] keep-bits
@@ -753,9 +754,28 @@ extern "C" int iqlhip_rows_gather_packed_h(const float* rows_dev, int64_t ld, co
 
 // ---------------------------------------------------------------------------
 // Policy inference: pack states -> forward of the policy instance only -> tanh / noise / scale / clamp.
+static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
+                              int64_t ld_noise, uint64_t rng_seed, uint64_t rng_call, float max_action,
+                              float* actions_dev, int64_t ld_a, void* stream);
+
 extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows,
                                     const float* noise_dev, int64_t ld_noise, float max_action, float* actions_dev,
                                     int64_t ld_a, void* stream) {
+  return actor_forward_impl(c, states_dev, ld_s, rows, noise_dev, ld_noise, 0, 0, max_action, actions_dev, ld_a, stream);
+}
+
+// dist.sample() with the noise drawn on the device: seed != 0 selects the stream, the library counts the calls.
+extern "C" int iqlhip_actor_sample(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows, uint64_t seed,
+                                   float max_action, float* actions_dev, int64_t ld_a, void* stream) {
+  if (!c) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (seed == 0) return fail(IQLHIP_EINVAL, "seed must be non-zero");
+  return actor_forward_impl(c, states_dev, ld_s, rows, nullptr, 0, seed, c->act_calls++, max_action, actions_dev, ld_a,
+                            stream);
+}
+
+static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
+                              int64_t ld_noise, uint64_t rng_seed, uint64_t rng_call, float max_action,
+                              float* actions_dev, int64_t ld_a, void* stream) {
   if (!c || !states_dev || !actions_dev) return fail(IQLHIP_EINVAL, "NULL argument");
   if (!c->params) return fail(IQLHIP_EINVAL, "iqlhip_bind has not been called");
   const int S = c->dims.state_dim, A = c->dims.action_dim;
@@ -777,7 +797,7 @@ extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int6
   launch_fwd_grid(c, p, n_rt * NSPLIT, st);
   hipLaunchKernelGGL(iql_actor_finish_kernel, dim3((rows * A + 255) / 256), dim3(256), 0, st, c->heads_act, rows, A,
                      max_action, p.log_std, c->hyper.log_std_min, c->hyper.log_std_max, noise_dev, (long long)ld_noise,
-                     actions_dev, (long long)ld_a);
+                     (unsigned long long)rng_seed, (unsigned long long)rng_call, actions_dev, (long long)ld_a);
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }

@@ -1666,17 +1666,31 @@ __global__ void iql_pack_states_kernel(float* xb, int ld, int S, int n, const fl
   }
 }
 
+// noise: caller-supplied N(0,1) values, or — rng_seed != 0 — drawn here: Philox4x32-10 keyed by the seed, counter
+// (element, call), Box-Muller on two of its words (the draw of dist.sample(), iql.py:376, without a host-side
+// random-number launch per env step).
 __global__ void iql_actor_finish_kernel(const float* heads_pi, int n, int A, float max_action, const float* log_std,
                                         float ls_min, float ls_max, const float* noise, long long ld_noise,
-                                        float* out, long long ld_out) {
+                                        unsigned long long rng_seed, unsigned long long rng_call, float* out,
+                                        long long ld_out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * A) return;
   const int row = e / A, dd = e - row * A;
   const f32x4 hp = *(const f32x4*)(heads_pi + (long long)e * NSPLIT);
   float a = tanh_via_exp(((hp[0] + hp[1]) + hp[2]) + hp[3]);      // same fixed order as the training step (sum4)
-  if (noise != nullptr) {
+  if (noise != nullptr || rng_seed != 0ull) {
     const float sigma = (log_std != nullptr) ? expf(fminf(fmaxf(log_std[dd], ls_min), ls_max)) : 0.f;
-    a = a + sigma * noise[row * ld_noise + dd];
+    float z;
+    if (noise != nullptr) {
+      z = noise[row * ld_noise + dd];
+    } else {
+      uint32_t c[4] = {(uint32_t)e, (uint32_t)rng_call, (uint32_t)(rng_call >> 32), 0xAC7u};
+      philox4x32_10(c, (uint32_t)rng_seed, (uint32_t)(rng_seed >> 32));
+      const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.f / 16777216.f);       // (0, 1)
+      const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+      z = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
+    a = a + sigma * z;
   }
   out[row * ld_out + dd] = fminf(fmaxf(a * max_action, -max_action), max_action);
 }

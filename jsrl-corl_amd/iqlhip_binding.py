@@ -86,6 +86,8 @@ SYMBOLS = [
     ("iqlhip_actor_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_float,
                                        C.c_void_p, C.c_int64, C.c_void_p]),
     ("iqlhip_rows_gather_packed", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("iqlhip_actor_sample", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float, C.c_void_p,
+                                      C.c_int64, C.c_void_p]),
     ("iqlhip_stream_synchronize", C.c_int, [C.c_void_p]),
     ("iqlhip_rows_gather_packed_h", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                               C.c_void_p]),

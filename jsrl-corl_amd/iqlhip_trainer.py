@@ -641,18 +641,27 @@ class ImplicitQLearning:
         n = x.shape[0]
         ma = float(self.max_action if max_action is None else max_action)
         out = torch.empty((n, self._A), dtype=torch.float32, device=self._dev)
-        noise = None
-        if sample and self._gaussian:
-            noise = torch.randn((n, self._A), dtype=torch.float32, device=self._dev)
+        draw = sample and self._gaussian          # dist.sample(): noise drawn on the device, seeded from torch's seed
         st = self._stream()
         cap = max(self._max_batch, hb.IQLHIP_ACT_ROWS)
         for r0 in range(0, n, cap):
             r1 = min(n, r0 + cap)
-            nz = noise[r0:r1] if noise is not None else None
-            hb.check(hb.lib().iqlhip_actor_forward(
-                self._ctx, x[r0:r1].data_ptr(), x.stride(0), r1 - r0, nz.data_ptr() if nz is not None else None,
-                self._A, ma, out[r0:r1].data_ptr(), out.stride(0), st))
+            if draw:
+                hb.check(hb.lib().iqlhip_actor_sample(self._ctx, x[r0:r1].data_ptr(), x.stride(0), r1 - r0,
+                                                      self._act_seed(), ma, out[r0:r1].data_ptr(), out.stride(0), st))
+            else:
+                hb.check(hb.lib().iqlhip_actor_forward(self._ctx, x[r0:r1].data_ptr(), x.stride(0), r1 - r0, None,
+                                                       self._A, ma, out[r0:r1].data_ptr(), out.stride(0), st))
         return out
+
+    def _act_seed(self) -> int:
+        """Non-zero 64-bit key of the device noise stream of act(): torch's seed at first use (so that
+        torch.manual_seed(s) before training gives a reproducible exploration stream)."""
+        k = getattr(self, "_act_key", None)
+        if k is None:
+            k = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0xAC7) & 0xFFFFFFFFFFFFFFFF
+            self._act_key = k = (k or 1)
+        return k
 
     def act_one(self, state: np.ndarray, max_action: float, sample: bool) -> np.ndarray:
         """actor.act(state): one state in, one action out.  The state is written into a pinned host buffer that the
@@ -661,21 +670,20 @@ class ImplicitQLearning:
         synchronisation — no staging copies, no per-call allocation."""
         self._require_gpu()
         if self._act_bufs is None:
-            self._act_bufs = (torch.empty((1, self._S), dtype=torch.float32).pin_memory(),
-                              torch.empty((1, self._A), dtype=torch.float32).pin_memory(),
-                              torch.empty((1, self._A), dtype=torch.float32, device=self._dev))
-        h_in, h_out, noise = self._act_bufs
-        h_in.numpy()[0, :] = np.asarray(state, dtype=np.float32).reshape(-1)
-        nz = None
-        if sample and self._gaussian:
-            with torch.cuda.device(self._dev):
-                noise.normal_()
-            nz = noise.data_ptr()
+            h_in = torch.empty((1, self._S), dtype=torch.float32).pin_memory()
+            h_out = torch.empty((1, self._A), dtype=torch.float32).pin_memory()
+            self._act_bufs = (h_in, h_out, h_in.numpy(), h_out.numpy())
+        h_in, h_out, in_np, out_np = self._act_bufs
+        in_np[0, :] = np.asarray(state, dtype=np.float32).reshape(-1)
         st = self._stream()
-        hb.check(hb.lib().iqlhip_actor_forward(self._ctx, h_in.data_ptr(), self._S, 1, nz, self._A, float(max_action),
-                                               h_out.data_ptr(), self._A, st))
+        if sample and self._gaussian:
+            hb.check(hb.lib().iqlhip_actor_sample(self._ctx, h_in.data_ptr(), self._S, 1, self._act_seed(),
+                                                  float(max_action), h_out.data_ptr(), self._A, st))
+        else:
+            hb.check(hb.lib().iqlhip_actor_forward(self._ctx, h_in.data_ptr(), self._S, 1, None, self._A,
+                                                   float(max_action), h_out.data_ptr(), self._A, st))
         hb.check(hb.lib().iqlhip_stream_synchronize(st))
-        return h_out.numpy().flatten().copy()
+        return out_np[0].copy()
 
     def set_timing(self, enabled: bool) -> None:
         self._require_gpu()
