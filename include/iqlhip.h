@@ -189,6 +189,10 @@ int iqlhip_rows_gather_packed(const float* rows_dev, int64_t ld, const int64_t* 
  * idx_scratch_dev on `stream`, then gathers.  idx_host must stay untouched until that copy has run. */
 int iqlhip_rows_gather_packed_h(const float* rows_dev, int64_t ld, const int64_t* idx_host, int64_t* idx_scratch_dev,
                                 int64_t n, float* out_rows_dev, void* stream);
+/* ... or in ordinary host memory: the library stages them through its own pinned ring (event-guarded) — the whole
+ * device side of ReplayBuffer.sample(batch_size) after the np.random.randint draw, in one call. */
+int iqlhip_rows_sample_packed(const float* rows_dev, int64_t ld, const int64_t* idx_host, int64_t n,
+                              float* out_rows_dev, void* stream);
 /* Device-side index draw used by iqlhip_train_steps, exposed for tests. */
 int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed, uint64_t offset, void* stream);
 

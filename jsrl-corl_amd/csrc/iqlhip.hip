@@ -752,6 +752,52 @@ extern "C" int iqlhip_rows_gather_packed_h(const float* rows_dev, int64_t ld, co
   return iqlhip_rows_gather_packed(rows_dev, ld, idx_scratch_dev, n, out_rows_dev, stream);
 }
 
+// ReplayBuffer.sample in one call from ORDINARY host memory (the array np.random.randint returned): the indices are
+// copied into a pinned ring slot owned by the library (guarded by an event, so a slot is never rewritten while its
+// H2D copy may still be queued), sent to a device scratch array on `stream`, and the rows gathered.  Per device
+// state, created on first use; like the rest of the ABI not thread-safe.
+namespace {
+struct SampleStage {
+  int device = -1;
+  int64_t cap = 0;
+  int64_t* host[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t* dev = nullptr;
+  int slot = 0;
+};
+SampleStage g_stage[16];
+}  // namespace
+
+extern "C" int iqlhip_rows_sample_packed(const float* rows_dev, int64_t ld, const int64_t* idx_host, int64_t n,
+                                         float* out_rows_dev, void* stream) {
+  if (!rows_dev || !idx_host || !out_rows_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (n < 0) return fail(IQLHIP_EINVAL, "bad rows_sample_packed geometry");
+  if (n == 0) return IQLHIP_OK;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail(IQLHIP_EUNSUPPORTED, "device index %d", dev);
+  SampleStage& sg = g_stage[dev];
+  if (sg.cap < n) {
+    HIPCHK(hipDeviceSynchronize());          // nothing may still read the old staging
+    for (int i = 0; i < 4; ++i) {
+      if (sg.host[i]) (void)hipHostFree(sg.host[i]);
+      if (!sg.done[i]) HIPCHK(hipEventCreateWithFlags(&sg.done[i], hipEventDisableTiming));
+    }
+    if (sg.dev) (void)hipFree(sg.dev);
+    sg.cap = std::max<int64_t>(n, 1024);
+    for (int i = 0; i < 4; ++i) HIPCHK(hipHostMalloc((void**)&sg.host[i], (size_t)sg.cap * sizeof(int64_t), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&sg.dev, (size_t)sg.cap * sizeof(int64_t)));
+    sg.device = dev;
+  }
+  const int k = sg.slot;
+  sg.slot = (sg.slot + 1) & 3;
+  HIPCHK(hipEventSynchronize(sg.done[k]));   // returns at once unless this slot's previous copy has not run yet
+  memcpy(sg.host[k], idx_host, (size_t)n * sizeof(int64_t));
+  HIPCHK(hipMemcpyAsync(sg.dev, sg.host[k], (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIPCHK(hipEventRecord(sg.done[k], (hipStream_t)stream));
+  return iqlhip_rows_gather_packed(rows_dev, ld, sg.dev, n, out_rows_dev, stream);
+}
+
 // ---------------------------------------------------------------------------
 // Policy inference: pack states -> forward of the policy instance only -> tanh / noise / scale / clamp.
 static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,

@@ -91,6 +91,7 @@ SYMBOLS = [
     ("iqlhip_stream_synchronize", C.c_int, [C.c_void_p]),
     ("iqlhip_rows_gather_packed_h", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                               C.c_void_p]),
+    ("iqlhip_rows_sample_packed", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("iqlhip_draw_indices", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
     ("iqlhip_debug_read", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),

@@ -180,33 +180,21 @@ class ReplayBuffer:
         # order: states, actions, rewards(B,1), next_states, dones(B,1)  (iql.py:171-178)
         if not self._gpu:
             return self.gather(self.sample_indices(batch_size))
-        # device side in ONE library call: pinned indices -> H2D copy -> packed row gather (same numpy draw, same
-        # rows as gather(sample_indices(n)))
+        # device side in ONE library call: numpy indices -> (library's pinned ring) -> H2D copy -> packed row gather
+        # (same numpy draw, same rows as gather(sample_indices(n)))
         indices = np.random.randint(0, self._index_bound(), size=batch_size)
-        ring = getattr(self, "_smp_ring", None)
-        if ring is None or ring[0][1].shape[0] < batch_size:
-            cap = max(batch_size, 256)
-            ring = []
-            for _ in range(4):
-                host = torch.empty(cap, dtype=torch.int64).pin_memory()
-                ring.append((host, host.numpy(), torch.cuda.Event()))
-            self._smp_ring, self._smp_slot = ring, 0
-            self._smp_dev = torch.empty(cap, dtype=torch.int64, device=self._rows.device)
-        host, host_np, done = ring[self._smp_slot]
-        self._smp_slot = (self._smp_slot + 1) % len(ring)
-        done.synchronize()            # no-op unless this slot's previous copy has not run yet
-        host_np[:batch_size] = indices
+        if indices.dtype != np.int64:
+            indices = indices.astype(np.int64)
         S, A = self._state_dim, self._action_dim
         dev = self._rows.device
         block = torch.empty((batch_size, self._ld), dtype=torch.float32, device=dev)
-        hb.check(hb.lib().iqlhip_rows_gather_packed_h(self._rows.data_ptr(), self._ld, host.data_ptr(),
-                                                      self._smp_dev.data_ptr(), batch_size, block.data_ptr(),
-                                                      self._stream()))
         if torch.cuda.current_device() == dev.index:
-            done.record()
+            hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows.data_ptr(), self._ld, indices.ctypes.data,
+                                                        batch_size, block.data_ptr(), self._stream()))
         else:
             with torch.cuda.device(dev):
-                done.record()
+                hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows.data_ptr(), self._ld, indices.ctypes.data,
+                                                            batch_size, block.data_ptr(), self._stream()))
         return [block[:, :S], block[:, S: S + A], block[:, 2 * S + A: 2 * S + A + 1], block[:, S + A: 2 * S + A],
                 block[:, 2 * S + A + 1: 2 * S + A + 2]]
 
