@@ -530,7 +530,7 @@ def test_actor_forward_chunks_ragged_and_after_training():
         assert np.max(np.abs(smp.std(0)[free] / sigma[free] - 1.0)) < 0.1
         zs = (smp[:, free] - mean[free]) / sigma[free]                      # device Box-Muller draws: N(0,1) shape
         assert abs(float(np.mean(zs ** 3))) < 0.15 and abs(float(np.mean(zs ** 4)) - 3.0) < 0.4
-        assert abs(float(np.corrcoef(zs[:-1, 0], zs[1:, 0])[0, 1])) < 0.06  # consecutive rows uncorrelated
+        assert abs(float(np.corrcoef(zs[:-1, 0], zs[1:, 0])[0, 1])) < 0.08  # consecutive rows uncorrelated (5 sigma)
     again = tr.actor_forward(torch.from_numpy(x).cuda(), sample=True).cpu().numpy()
     assert not np.array_equal(again, smp)                                   # the call counter advances the stream
 
