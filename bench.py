@@ -9,23 +9,29 @@ A "step" is one pass of the hot path over one batch: draw 256 row indices
 7 MLP forwards, 3 losses, backward, Adam x3, Polyak.  Inputs are synthetic
 D4RL-shaped rows resident in HBM before the timed region starts.
 
-N = 1: BASELINE.json configs[1] (obs=17, act=6, 1M rows, batch=256): K steps replayed
-       as hipGraph chunks (ImplicitQLearning.train_steps).
-N > 1: configs[3]-style data parallelism at fixed per-GPU batch 256 (global batch 256*N,
-       weak scaling): per-rank device index draw, forward+backward, RCCL all-reduce of the
-       flat gradient, fused Adam/Polyak on every rank (ImplicitQLearning.train_on_buffer).
+N = 1: BASELINE.json configs[1] (obs=17, act=6, 1M rows, batch=256).
+N > 1: BASELINE.json configs[3] (obs=17, act=6, 10M-row buffer replicated per GPU, global batch 256*N sharded
+       over the ranks — weak scaling at 256 rows per GPU): per-rank device index draw, forward+backward, exchange
+       of the flat gradient over xGMI, fused Adam/Polyak on every rank.  The exchange is either RCCL's all-reduce or
+       the library's direct peer-read exchange; both run inside the captured step graphs, --exchange picks one,
+       the default ("auto") times both in the warm-up and keeps the faster one that left the replicas identical.
        value = batch-256 gradient computations per second summed over ranks.
+       Launched without torch.distributed.run (WORLD_SIZE unset), `--gpus N` spawns the N rank processes itself.
 
-Prints ONE JSON line on rank 0 (contract in the round prompt) with `roofline` (the
-backward kernel, the step's dominant launch, against the fp32-MFMA peak) and, at N = 1,
-`cpu_baseline` (oracle/iql_torch_port.py — a PyTorch-CPU port of the reference step —
-timed on the host cores for a bounded ~20 s sample).
+The timed region never contains a graph capture or instantiation for ANY --steps/--warmup: the library composes a
+run from replays of one 64-step chunk graph (captured, instantiated and uploaded by prepare_train_steps before
+the warm-up) plus directly launched steps.
+
+Prints ONE JSON line on rank 0 (contract in the round prompt) with `roofline` (the backward kernel, the step's
+dominant launch, against the fp32-MFMA peak) and, at N = 1, `cpu_baseline` (oracle/iql_torch_port.py — a PyTorch-CPU
+port of the reference step — timed on the host cores for a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,7 +41,11 @@ for p in (ROOT, os.path.join(ROOT, "jsrl-corl_amd")):
         sys.path.insert(0, p)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 HID = 256
+ROWS_1GPU = 1_000_000          # BASELINE.json configs[1]
+ROWS_DP = 10_000_000           # BASELINE.json configs[3]
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
 def flops(S, A, B):
@@ -48,26 +58,85 @@ def flops(S, A, B):
     return fwd, bwd
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--rows", type=int, default=0, help="buffer rows (default: 1M at --gpus 1, 10M per GPU above)")
     ap.add_argument("--state-dim", type=int, default=17)
     ap.add_argument("--action-dim", type=int, default=6)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
                     help="f32 = the parity path (headline); bf16 = bf16 operands / fp32 accumulate in the 256-deep products")
+    ap.add_argument("--exchange", choices=("auto", "rccl", "p2p"), default="auto",
+                    help="N > 1: gradient exchange (auto = time both in the warm-up, keep the faster valid one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="print the rank fan-out this invocation would start (JSON) and exit; touches no GPU")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
 
+
+def launch_plan(args, argv):
+    """The N child processes `--gpus N` starts when no launcher set WORLD_SIZE: one per GPU, rank = local rank = GPU
+    index, rendezvous on 127.0.0.1.  Returned as data so that a CPU test can check it without starting anything."""
+    port = args.master_port or (29500 + os.getpid() % 2000)
+    child_argv = [a for a in argv if a != "--dry-run-launch"]
+    plan = []
+    for r in range(args.gpus):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+        plan.append({"rank": r, "cmd": [sys.executable, os.path.abspath(__file__)] + child_argv, "env": env})
+    return plan
+
+
+def spawn_ranks(args, argv) -> int:
+    """Parent of a self-launched multi-GPU run.  It has not touched the GPU (no torch import, no HIP call) and never
+    will: the ranks are fresh child processes; rank 0's stdout (the JSON line) is passed through."""
+    plan = launch_plan(args, argv)
+    procs = []
+    for item in plan:
+        env = dict(os.environ)
+        env.update(item["env"])
+        out = None if item["rank"] == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen(item["cmd"], env=env, stdout=out))
+    rc = 0
+    for pr in procs:
+        pr.wait()
+        rc = rc or pr.returncode
+    if rc:                                            # one rank failed: do not leave the others waiting in a collective
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.dry_run_launch:
+        plan = launch_plan(args, argv) if (env_world is None and args.gpus > 1) else []
+        print(json.dumps({"gpus": args.gpus, "self_launch": bool(plan), "ranks": plan,
+                          "rows": args.rows or (ROWS_1GPU if args.gpus == 1 else ROWS_DP)}))
+        return 0
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args, argv)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)\n")
+        return 2
+    return run_rank(args, world)
+
+
+def run_rank(args, world: int) -> int:
     import numpy as np
     import torch
 
     import __graft_entry__ as ge
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -91,14 +160,15 @@ def main():
     import synth
 
     S, A, B = args.state_dim, args.action_dim, args.batch
+    rows = args.rows or (ROWS_1GPU if world == 1 else ROWS_DP)
     dev = f"cuda:{dev_index}"
     torch.cuda.set_device(dev_index)
 
-    # ---- synthetic HBM-resident buffer + nets (seed 0)
-    data = synth.synth_transitions(args.rows, S, A, seed=0)
-    buf = iql.ReplayBuffer(S, A, args.rows, dev)
+    # ---- synthetic HBM-resident buffer + nets (seed 0; every rank holds the same replicated buffer)
     import contextlib
     import io
+    buf = iql.ReplayBuffer(S, A, rows, dev)
+    data = synth.synth_transitions(rows, S, A, seed=0)
     with contextlib.redirect_stdout(io.StringIO()):
         buf.load_d4rl_dataset(data)
     del data
@@ -109,23 +179,9 @@ def main():
         q_network=qf, q_optimizer=torch.optim.Adam(qf.parameters(), lr=3e-4),
         v_network=vf, v_optimizer=torch.optim.Adam(vf.parameters(), lr=3e-4),
         iql_tau=0.7, beta=3.0, max_steps=1_000_000, discount=0.99, tau=0.005, device=dev)
+    tr.reserve_batch(B)
     if args.precision == "bf16":
         tr.set_precision("bf16")
-    force_dp = os.environ.get("IQLHIP_BENCH_FORCE_DP") == "1"   # diagnostic: 1-rank process group, DP code path
-    if force_dp and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29731")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
-        tr._dp_world, tr._dp_group = 2, None      # take the split path; the collective runs over 1 rank
-        tr._dp_world_scale = 1
-    if world > 1:
-        tr.enable_data_parallel()
-
-    def run(n):
-        if world > 1 or force_dp:
-            tr.train_steps_dp(buf, n, B, seed=1234)
-        else:
-            tr.train_steps(buf, n, B, seed=1234, return_losses=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -133,27 +189,78 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def run(n):
+        tr.train_steps(buf, n, B, seed=1234, return_losses=False)
 
-    # sanity: the run trained (losses finite)
+    def timed(n):
+        fence()
+        t = time.perf_counter()
+        run(n)
+        fence()
+        t = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
+
+    def replicas_equal() -> bool:
+        """All ranks hold bit-identical parameters and no peer wait timed out."""
+        p = tr._params_arena.view(torch.int32).to(torch.int64)
+        sig = torch.stack([p.sum(), (p * torch.arange(1, p.numel() + 1, device=p.device)).sum()])
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        bad = torch.tensor([0 if tr.exchange_status()["timed_out_step"] == 0 else 1], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        return bool(torch.equal(lo, hi)) and int(bad.item()) == 0
+
+    # ---- exchange (N > 1): attach, pre-capture, pick
+    exchange, probe = None, {}
+    warm = args.warmup
+    if world > 1:
+        want = args.exchange
+        tr.enable_data_parallel(exchange={"auto": "both", "rccl": "rccl", "p2p": "p2p"}[want])
+        modes = ["p2p", "rccl"] if want == "auto" else [want]
+        for m in modes:
+            tr.select_exchange(m)
+            tr.prepare_train_steps(buf, B)
+        if want == "auto":
+            # the warm-up steps are split between the two exchanges and timed; the faster one that kept the replicas
+            # bit-identical runs the timed region.  (Too few warm-up steps to tell: RCCL, the vendor's collective.)
+            half = warm // 2
+            if half >= 8:
+                for m in modes:
+                    tr.select_exchange(m)
+                    t = timed(half)
+                    probe[m] = {"steps_per_s": round(half * world / t, 1), "replicas_equal": replicas_equal()}
+                warm -= 2 * half
+                ok = [m for m in modes if probe[m]["replicas_equal"]]
+                exchange = max(ok, key=lambda m: probe[m]["steps_per_s"]) if ok else "rccl"
+            else:
+                exchange = "rccl"
+            tr.select_exchange(exchange)
+        else:
+            exchange = want
+    else:
+        tr.prepare_train_steps(buf, B)       # capture + instantiate + upload the chunk graph: never in the timed region
+
+    if warm > 0:
+        run(warm)
+    dt = timed(args.steps)
+
+    # sanity: the run trained (losses finite), replicas still identical
     log = tr.train(buf.sample(B)) if world == 1 else tr.train_on_buffer(buf, B, seed=1, sync=True)
     assert all(np.isfinite(v) for v in log.values()), log
+    if world > 1:
+        assert replicas_equal(), "replicas diverged or a peer wait timed out"
 
     # ---- roofline of the dominant kernel (backward): its average launch duration is measured live with
     # HIP events on the launch stream around back-to-back launches of that kernel on the bench batch
     # (iqlhip_debug_time_kernel; events around single ~10 us launches would add their own ~3 us).
     f_fwd, f_bwd = flops(S, A, B)
     roof = None
-    if world == 1:
+    if rank == 0:
         batch = buf.sample(B)
         t_fwd = tr.time_kernel(batch, 0, 500)
         t_bwd = tr.time_kernel(batch, 1, 500)
@@ -163,30 +270,37 @@ def main():
         # --pmc WRITE_SIZE in separate runs of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950
         # correction; tools/pmc_traffic.py).  Only valid for the default workload.
         traffic, mfma_util = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
-        if os.path.exists(pmc) and (S, A, B) == (17, 6, 256) and args.precision == "f32":
-            with open(pmc) as fh:
+        if os.path.exists(PMC_SUMMARY) and (S, A, B) == (17, 6, 256) and args.precision == "f32":
+            with open(PMC_SUMMARY) as fh:
                 for name, rec in json.load(fh).items():
                     if "iql_bwd_kernel" in name:
                         traffic = rec.get("hbm_bytes_per_launch_corrected")
                         mfma_util = rec.get("mfma_util")      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)
-        roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        peak = PEAK_F32_MFMA_TFLOPS     # (bf16 mode keeps fp32 MFMAs outside the three 256-deep products; priced against fp32)
+        roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None if traffic is None else round(traffic),
                 "mfma_util_pmc": None if mfma_util is None else round(mfma_util, 4),
                 "flops_per_launch": f_bwd, "avg_launch_us": round(t_bwd, 3),
                 "kernel_us": {"iql_fwd_kernel": round(t_fwd, 3), "iql_bwd_kernel": round(t_bwd, 3),
                               "iql_update_kernel": round(t_upd, 3)},
                 "step_flops": f_fwd + f_bwd,
-                "step_frac_of_peak": round((f_fwd + f_bwd) * args.steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                "step_frac_of_peak": round((f_fwd + f_bwd) * args.steps / dt / 1e12 / peak, 4)}
 
     if rank != 0:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
 
     value = args.steps * world / dt
+    cfg = {"workload": f"IQL step on synthetic buffer (obs={S}, act={A}, {rows} rows), batch={B} per GPU",
+           "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
+           "global_steps_per_s": round(args.steps / dt, 1)}
+    if world > 1:
+        cfg["exchange"] = exchange
+        if probe:
+            cfg["exchange_probe"] = probe
     out = {
         "metric": "IQL gradient-steps/sec at batch=256 (D4RL obs/act dims)",
         "value": round(value, 1),
@@ -200,30 +314,34 @@ def main():
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic",
-        "config": {"workload": f"IQL step on synthetic buffer (obs={S}, act={A}, {args.rows} rows), batch={B} per GPU",
-                   "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "global_steps_per_s": round(args.steps / dt, 1)},
+        "config": cfg,
     }
     if roof:
         out["roofline"] = roof
     if world == 1 and not args.no_cpu_baseline:
         from oracle import iql_torch_port as port
-        ncpu = os.cpu_count() or 1
-        sps1, n1, el1 = port.time_cpu_steps(S, A, B, min(args.rows, 200_000), seconds_budget=args.cpu_seconds, threads=1)
-        thr = min(ncpu, 16)
-        spsN, nN, elN = port.time_cpu_steps(S, A, B, min(args.rows, 200_000), seconds_budget=args.cpu_seconds, threads=thr)
-        best, cores = (sps1, 1) if sps1 >= spsN else (spsN, thr)
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        cpu_rows = min(rows, 1_000_000)
+        runs = []
+        for thr in sorted({1, min(ncpu, 16), ncpu}):
+            sps, n, el = port.time_cpu_steps(S, A, B, cpu_rows, seconds_budget=args.cpu_seconds, threads=thr)
+            runs.append((sps, thr, n, el))
+        best, cores, _, _ = max(runs)
         out["cpu_baseline"] = {
             "value": round(best, 2), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"PyTorch-CPU port of the reference step (oracle/iql_torch_port.py), same S/A/B, 200k-row buffer: "
-                      f"{n1} steps in {el1:.1f}s @1 thread = {sps1:.1f}/s; {nN} steps in {elN:.1f}s @{thr} threads = {spsN:.1f}/s; "
-                      f"torch {torch.__version__}, {ncpu} host cpus"}
+            "sample": f"PyTorch-CPU port of the reference step (oracle/iql_torch_port.py), same S/A/B, {cpu_rows}-row buffer: "
+                      + "; ".join(f"{n} steps in {el:.1f}s @{thr} thread(s) = {sps:.1f}/s" for sps, thr, n, el in runs)
+                      + f"; torch {torch.__version__}, {ncpu} host cpus available to the process"}
         out["speedup_vs_cpu"] = round(value / best, 1)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -29,10 +29,12 @@
 extern "C" {
 #endif
 
-#define IQLHIP_VERSION 100          /* 0.1.0 */
+#define IQLHIP_VERSION 200          /* 0.2.0 */
 #define IQLHIP_HIDDEN 256           /* hidden width the kernels are tiled for (reference default, iql.py:352) */
 #define IQLHIP_MAX_INPUT 128        /* max state_dim + action_dim */
 #define IQLHIP_MAX_ACTION 32        /* max action_dim */
+#define IQLHIP_MAX_WORLD 8          /* ranks of one data-parallel group (the GPUs of one node) */
+#define IQLHIP_GRAPH_STEPS 64       /* steps per captured hipGraph chunk of iqlhip_train_steps */
 
 enum {
   IQLHIP_OK = 0,
@@ -163,6 +165,44 @@ int64_t iqlhip_grad_words(const iqlhip_ctx* ctx);   /* n_params + 4 */
 int iqlhip_train_steps(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int64_t size, int32_t batch_rows,
                        const iqlhip_step_scalars* sc, int32_t n_steps, uint64_t seed, uint64_t stream_offset,
                        void* stream);
+
+/* Capture, instantiate and upload the hipGraph chunk iqlhip_train_steps replays for this (buffer, batch_rows,
+ * inv_batch) — and, with an exchange attached, this exchange mode — WITHOUT running a step, so that no later
+ * iqlhip_train_steps call pays for it (bench.py calls it before its timed region).  iqlhip_train_steps composes a run
+ * of n steps from floor(n / IQLHIP_GRAPH_STEPS) replays of that one chunk graph and n % IQLHIP_GRAPH_STEPS steps
+ * launched directly, so its cost per step does not depend on n and nothing is ever captured per value of n. */
+int iqlhip_train_steps_prepare(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int32_t batch_rows, float inv_batch);
+
+/* ---- data-parallel gradient exchange (the reference has no multi-device code) ----------------
+ * One process per GPU.  With an exchange attached, iqlhip_step and iqlhip_train_steps run, per step:
+ * forward, backward, flatten (this rank's flat gradient: n_params floats + 4 tail words with the loss
+ * contributions; batch means divided by the GLOBAL row count: sc->inv_batch = 1 / (batch_rows * world)), the
+ * exchange, and the fused Adam / Polyak update on the summed gradient — all on `stream`, inside the captured chunk
+ * graphs too.  Two exchanges:
+ *   RCCL  ncclAllReduce(sum, fp32) of the flat buffer, in place, in-stream (iqlhip_allreduce_init).
+ *   P2P   every rank's flat buffers are mapped into every other rank (hipIpc); after a flag handshake in device
+ *         memory the update kernel reads all ranks' buffers directly over xGMI and sums them in rank order
+ *         (iqlhip_p2p_export + iqlhip_p2p_attach).  No collective library call per step. */
+enum { IQLHIP_XCH_NONE = 0, IQLHIP_XCH_RCCL = 1, IQLHIP_XCH_P2P = 2 };
+#define IQLHIP_UNIQUE_ID_BYTES 128  /* = NCCL_UNIQUE_ID_BYTES */
+#define IQLHIP_IPC_HANDLE_BYTES 64  /* = sizeof(hipIpcMemHandle_t) */
+/* ncclGetUniqueId: called by ONE rank; the caller ships the 128 bytes to the others (any channel). */
+int iqlhip_comm_unique_id(void* id_out);
+/* ncclCommInitRank on the context's device; collective over the `world` ranks.  Selects the RCCL exchange. */
+int iqlhip_allreduce_init(iqlhip_ctx* ctx, const void* unique_id, int rank, int world);
+/* P2P exchange, step 1: allocate this rank's exchange block (flags + two flat buffers) and export it
+ * (hipIpcGetMemHandle) into handle_out[IQLHIP_IPC_HANDLE_BYTES]; the caller all-gathers the handles. */
+int iqlhip_p2p_export(iqlhip_ctx* ctx, void* handle_out, int rank, int world);
+/* step 2: map the peers' blocks (handles = world x IQLHIP_IPC_HANDLE_BYTES in rank order; the own slot is ignored).
+ * Selects the P2P exchange.  timeout_ms bounds every in-stream wait for a peer (0 = 5000). */
+int iqlhip_p2p_attach(iqlhip_ctx* ctx, const void* handles, int timeout_ms);
+/* Switch between attached exchanges (IQLHIP_XCH_*); NONE detaches nothing, it only runs steps locally. */
+int iqlhip_xch_select(iqlhip_ctx* ctx, int mode);
+/* status[0] = mode in use, status[1] = first step at which a P2P wait timed out (0 = never), status[2] = steps
+ * exchanged so far.  Synchronises `stream`. */
+int iqlhip_xch_status(iqlhip_ctx* ctx, int64_t status[3], void* stream);
+/* Release communicator / peer mappings (also done by iqlhip_destroy). */
+int iqlhip_xch_shutdown(iqlhip_ctx* ctx);
 
 /* The three .item() calls of iql.py:491,509,535: synchronises `stream`. out = {value,q,actor}. */
 int iqlhip_read_losses(iqlhip_ctx* ctx, float out[3], void* stream);

@@ -2,12 +2,17 @@
 // arena layout, scratch management, launches, hipGraph capture of K-step chunks.
 #include "iqlhip_kernels.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+
+#define GRAPH_STEPS IQLHIP_GRAPH_STEPS
 
 static thread_local std::string g_err;
 
@@ -29,15 +34,44 @@ static int fail(int code, const char* fmt, ...) {
 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Make the context's GPU the current HIP device for the duration of an entry point and restore the caller's
+// afterwards (a trainer on cuda:1 may be driven while cuda:0 is current; the library must not change that).
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+// What a captured chunk graph (GRAPH_STEPS steps) depends on through frozen kernel arguments.  The number of steps
+// of a call is NOT part of it: a call is composed of replays of the one chunk graph plus directly launched steps.
 struct GraphKey {
   const float* rows = nullptr;
   int64_t ld = 0;
-  int32_t B = 0, K = 0;
+  int32_t B = 0;
   float* params = nullptr;
   float drop_p = 0.f;
+  float inv_batch = 0.f;
+  int xch = 0;        // exchange mode the chunk was captured with
+  int parity = 0;     // P2P exchange: which flat buffer step 0 of the chunk writes
   bool operator==(const GraphKey& o) const {
-    return rows == o.rows && ld == o.ld && B == o.B && K == o.K && params == o.params && drop_p == o.drop_p;
+    return rows == o.rows && ld == o.ld && B == o.B && params == o.params && drop_p == o.drop_p &&
+           inv_batch == o.inv_batch && xch == o.xch && parity == o.parity;
   }
+};
+
+// The few RCCL entry points the in-stream all-reduce needs, resolved at run time from the librccl.so.1 the process
+// already has (PyTorch-ROCm brings one) or can load — the library has no link-time dependency on RCCL.
+struct RcclId { char internal[IQLHIP_UNIQUE_ID_BYTES]; };
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId /* ncclUniqueId, by value */, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
 };
 
 struct iqlhip_ctx {
@@ -67,9 +101,12 @@ struct iqlhip_ctx {
   int precision = 0;                  // 0: fp32 MFMA everywhere; 1: bf16 operands for the 256-deep products
   float* loss_ring = nullptr;         // [ring_cap][4]
   int ring_cap = 0;
-  long long* idx_chunk = nullptr;     // [K_max * max_batch]
-  iqlhip_step_scalars* sched = nullptr;  // [K_max]
-  unsigned long long* hdr = nullptr;  // {size, seed, offset}
+  long long* idx_chunk = nullptr;     // [GRAPH_STEPS * max_batch] row indices of the chunk in flight
+  iqlhip_step_scalars* sched_cur = nullptr;   // [GRAPH_STEPS] device: per-step scalars of the chunk in flight
+  iqlhip_step_scalars* sched_pin[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned, host-mapped copies of a call's table [k_max]
+  hipEvent_t sched_done[4] = {nullptr, nullptr, nullptr, nullptr};           // slot free again once this event has passed
+  int sched_slot = 0;
+  unsigned long long* hdr = nullptr;  // [HDR_WORDS] per-launch values of a chunk (ChunkHdr)
   unsigned long long* stamps = nullptr;  // diagnostic builds (-DIQL_STAMPS): [4096 blocks][16]
   int k_max = 0;
   int n_chunk_max = 0, n_rt_max = 0;
@@ -78,9 +115,22 @@ struct iqlhip_ctx {
   int w0_lds_k = 0;                   // widest layer-0 input whose weights the forward stages in LDS
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
   hipStream_t cap_stream = nullptr;
-  struct CachedGraph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; };
+  struct CachedGraph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; hipStream_t last; };
   std::vector<CachedGraph> graphs;
   unsigned long long graph_clock = 0;
+  // data-parallel gradient exchange
+  int xch_mode = IQLHIP_XCH_NONE;
+  int rank = 0, world = 1;
+  float* xflat = nullptr;             // RCCL / split path: this rank's flat gradient [n_params + 4] (+ pad)
+  void* nccl_comm = nullptr;
+  // P2P: one exchange block per rank = [flags: IQLHIP_MAX_WORLD x 16 u64][flat 0][flat 1], exported through hipIpc
+  char* xblk = nullptr;
+  size_t xblk_bytes = 0, xflat_off[2] = {0, 0};
+  char* peer_blk[IQLHIP_MAX_WORLD] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool p2p_attached = false;
+  unsigned long long* xstatus = nullptr;   // device: [0] first timed-out step, [1] spare
+  unsigned long long xstep = 0;            // steps exchanged so far (the P2P flags count them)
+  unsigned long long xtimeout_ticks = 500000000ull;   // 5 s of the 100 MHz wall clock
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;         // 4 per recorded step
@@ -139,15 +189,10 @@ extern "C" int64_t iqlhip_row_stride(int32_t S, int32_t A) { return up(2 * (int6
 
 static int xld_host(int k0) { int k0p = (k0 + 3) & ~3; return ((k0p + 29) / 32) * 32 + 2; }
 
-extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper, int device, iqlhip_ctx** out) {
-  int rc = check_dims(dims);
-  if (rc) return rc;
-  if (!hyper || !out) return fail(IQLHIP_EINVAL, "hyper/out is NULL");
-  int ndev = 0;
-  HIPCHK(hipGetDeviceCount(&ndev));
-  if (device < 0 || device >= ndev) return fail(IQLHIP_EHIP, "device %d not available (%d visible)", device, ndev);
-  HIPCHK(hipSetDevice(device));
-  iqlhip_ctx* c = new iqlhip_ctx();
+extern "C" int iqlhip_destroy(iqlhip_ctx* c);
+extern "C" int iqlhip_xch_shutdown(iqlhip_ctx* c);
+
+static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hyper* hyper, int device) {
   c->dims = *dims;
   c->hyper = *hyper;
   c->device = device;
@@ -186,9 +231,17 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   c->k_max = 1024;
   c->ring_cap = c->k_max;
   HIPCHK(dalloc(&c->loss_ring, (size_t)c->ring_cap * 4));
-  HIPCHK(hipMalloc((void**)&c->idx_chunk, (size_t)c->k_max * MB * sizeof(long long)));
-  HIPCHK(hipMalloc((void**)&c->sched, (size_t)c->k_max * sizeof(iqlhip_step_scalars)));
-  HIPCHK(hipMalloc((void**)&c->hdr, 4 * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void**)&c->idx_chunk, (size_t)GRAPH_STEPS * MB * sizeof(long long)));
+  HIPCHK(hipMalloc((void**)&c->sched_cur, (size_t)GRAPH_STEPS * sizeof(iqlhip_step_scalars)));
+  for (int i = 0; i < 4; ++i) {
+    HIPCHK(hipHostMalloc((void**)&c->sched_pin[i], (size_t)c->k_max * sizeof(iqlhip_step_scalars), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&c->sched_done[i], hipEventDisableTiming));
+  }
+  HIPCHK(hipMalloc((void**)&c->hdr, HDR_WORDS * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->hdr, 0, HDR_WORDS * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void**)&c->xstatus, 2 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->xstatus, 0, 2 * sizeof(unsigned long long)));
+  HIPCHK(dalloc(&c->xflat, (size_t)up(c->L.n_params + 4, 64)));
   HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
 #ifdef IQL_STAMPS
   HIPCHK(hipMalloc((void**)&c->stamps, 4096 * 16 * sizeof(unsigned long long)));
@@ -226,12 +279,32 @@ extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper,
   HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
   HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
   HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper, int device, iqlhip_ctx** out) {
+  int rc = check_dims(dims);
+  if (rc) return rc;
+  if (!hyper || !out) return fail(IQLHIP_EINVAL, "hyper/out is NULL");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(IQLHIP_EHIP, "device %d not available (%d visible)", device, ndev);
+  DevGuard guard(device);               // the caller's current device is restored on return
+  iqlhip_ctx* c = new iqlhip_ctx();
+  rc = create_impl(c, dims, hyper, device);
+  if (rc) {                             // free whatever was allocated before the failure (the message survives)
+    const std::string msg = g_err;
+    iqlhip_destroy(c);
+    g_err = msg;
+    return rc;
+  }
   *out = c;
   return IQLHIP_OK;
 }
 
 static void drop_graph(iqlhip_ctx* c) {
   for (auto& g : c->graphs) {
+    if (g.last) (void)hipStreamSynchronize(g.last);   // a replay may still be executing
     (void)hipGraphExecDestroy(g.exec);
     (void)hipGraphDestroy(g.graph);
   }
@@ -240,14 +313,20 @@ static void drop_graph(iqlhip_ctx* c) {
 
 extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   if (!c) return IQLHIP_OK;
-  (void)hipSetDevice(c->device);
+  DevGuard guard(c->device);
   (void)hipDeviceSynchronize();
   drop_graph(c);
+  (void)iqlhip_xch_shutdown(c);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
-                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act, c->heads_act, c->drop_bits};
-  for (void* b : bufs) (void)hipFree(b);
+                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched_cur, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act,
+                  c->heads_act, c->drop_bits, c->xstatus, c->xflat};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  for (int i = 0; i < 4; ++i) {
+    if (c->sched_pin[i]) (void)hipHostFree(c->sched_pin[i]);
+    if (c->sched_done[i]) (void)hipEventDestroy(c->sched_done[i]);
+  }
   if (c->losses_host) (void)hipHostFree(c->losses_host);
   delete c;
   return IQLHIP_OK;
@@ -428,6 +507,9 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.sched_idx = 0;
   u.n_upd_blocks = (int)((c->L.n_params / 4 + 255) / 256);
   u.d_bits = nullptr; u.d_n_words = 2 * c->dims.max_batch * 8; u.d_thresh = 0; u.d_hdr = c->hdr; u.d_k = 0;
+  u.ring_hdr = nullptr;
+  u.n_peer = 0;
+  for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) u.peer_flat[r] = nullptr;
   return u;
 }
 
@@ -473,8 +555,215 @@ static void launch_dropmask(const iqlhip_ctx* c, unsigned long long seed, unsign
 static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
   int nb = u.n_upd_blocks;
   if (u.d_bits) nb += (u.d_n_words + 255) / 256;                               // next step's dropout keep-bits
-  if (u.sched) hipLaunchKernelGGL(iql_update_kernel<true>, dim3(nb), dim3(256), 0, st, u);
-  else hipLaunchKernelGGL(iql_update_kernel<false>, dim3(nb), dim3(256), 0, st, u);
+  const bool peer = u.n_peer > 0;
+  if (u.sched) {
+    if (peer) hipLaunchKernelGGL((iql_update_kernel<true, true>), dim3(nb), dim3(256), 0, st, u);
+    else hipLaunchKernelGGL((iql_update_kernel<true, false>), dim3(nb), dim3(256), 0, st, u);
+  } else {
+    if (peer) hipLaunchKernelGGL((iql_update_kernel<false, true>), dim3(nb), dim3(256), 0, st, u);
+    else hipLaunchKernelGGL((iql_update_kernel<false, false>), dim3(nb), dim3(256), 0, st, u);
+  }
+}
+
+static void launch_flatten(const iqlhip_ctx* c, const UpdParams& u, float* out, bool sys, hipStream_t st) {
+  const int nb = (int)((c->L.n_params / 4 + 255) / 256);
+  if (sys) hipLaunchKernelGGL(iql_grad_flatten_kernel<true>, dim3(nb), dim3(256), 0, st, u, out);
+  else hipLaunchKernelGGL(iql_grad_flatten_kernel<false>, dim3(nb), dim3(256), 0, st, u, out);
+}
+
+// ---------------------------------------------------------------------------
+// Gradient exchange between the ranks of a data-parallel group (include/iqlhip.h, "data-parallel gradient exchange").
+static RcclApi g_rccl;
+
+static int rccl_load() {
+  if (g_rccl.lib) return IQLHIP_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);      // the copy the process already has (PyTorch-ROCm's)
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW);
+  if (!h) return fail(IQLHIP_EHIP, "librccl.so.1 not found: %s", dlerror());
+  RcclApi a;
+  a.lib = h;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce)
+    return fail(IQLHIP_EHIP, "librccl.so.1 lacks an expected symbol");
+  g_rccl = a;
+  return IQLHIP_OK;
+}
+#define NCCLCHK(expr)                                                                              \
+  do {                                                                                             \
+    int r_ = (expr);                                                                               \
+    if (r_ != 0)                                                                                   \
+      return fail(IQLHIP_EHIP, "%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); \
+  } while (0)
+enum { RCCL_FLOAT32 = 7, RCCL_SUM = 0 };     // ncclFloat32, ncclSum (rccl.h)
+
+extern "C" int iqlhip_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(IQLHIP_EINVAL, "NULL argument");
+  int rc = rccl_load();
+  if (rc) return rc;
+  NCCLCHK(g_rccl.GetUniqueId(id_out));
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_allreduce_init(iqlhip_ctx* c, const void* unique_id, int rank, int world) {
+  if (!c || !unique_id) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(IQLHIP_EINVAL, "rank %d outside world %d", rank, world);
+  if (c->p2p_attached && (world != c->world || rank != c->rank))
+    return fail(IQLHIP_EINVAL, "rank/world differ from the attached P2P exchange");
+  int rc = rccl_load();
+  if (rc) return rc;
+  DevGuard guard(c->device);
+  if (c->nccl_comm) { (void)g_rccl.CommDestroy(c->nccl_comm); c->nccl_comm = nullptr; }
+  RcclId id;
+  memcpy(&id, unique_id, sizeof id);
+  NCCLCHK(g_rccl.CommInitRank(&c->nccl_comm, world, id, rank));
+  c->rank = rank;
+  c->world = world;
+  c->xch_mode = IQLHIP_XCH_RCCL;
+  drop_graph(c);
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_p2p_export(iqlhip_ctx* c, void* handle_out, int rank, int world) {
+  if (!c || !handle_out) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (world < 1 || world > IQLHIP_MAX_WORLD || rank < 0 || rank >= world)
+    return fail(IQLHIP_EINVAL, "rank %d / world %d outside [0, %d]", rank, world, IQLHIP_MAX_WORLD);
+  if (c->nccl_comm && (world != c->world || rank != c->rank))
+    return fail(IQLHIP_EINVAL, "rank/world differ from the RCCL communicator");
+  DevGuard guard(c->device);
+  if (!c->xblk) {
+    const size_t flags_b = 4096;                                     // IQLHIP_MAX_WORLD x 128-B flag lines, padded
+    const size_t flat_b = (size_t)up((c->L.n_params + 4) * (int64_t)sizeof(float), 4096);
+    c->xflat_off[0] = flags_b;
+    c->xflat_off[1] = flags_b + flat_b;
+    c->xblk_bytes = flags_b + 2 * flat_b;
+    HIPCHK(hipMalloc((void**)&c->xblk, c->xblk_bytes));
+    HIPCHK(hipMemset(c->xblk, 0, c->xblk_bytes));
+    HIPCHK(hipDeviceSynchronize());
+  }
+  hipIpcMemHandle_t h;
+  static_assert(sizeof(hipIpcMemHandle_t) == IQLHIP_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  HIPCHK(hipIpcGetMemHandle(&h, c->xblk));
+  memcpy(handle_out, &h, sizeof h);
+  c->rank = rank;
+  c->world = world;
+  return IQLHIP_OK;
+}
+
+static void p2p_close(iqlhip_ctx* c) {
+  for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) {
+    if (c->peer_blk[r] && c->peer_blk[r] != c->xblk) (void)hipIpcCloseMemHandle(c->peer_blk[r]);
+    c->peer_blk[r] = nullptr;
+  }
+  c->p2p_attached = false;
+}
+
+extern "C" int iqlhip_p2p_attach(iqlhip_ctx* c, const void* handles, int timeout_ms) {
+  if (!c || !handles) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (!c->xblk) return fail(IQLHIP_EINVAL, "iqlhip_p2p_export has not been called");
+  DevGuard guard(c->device);
+  p2p_close(c);
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) { c->peer_blk[r] = c->xblk; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles + (size_t)r * IQLHIP_IPC_HANDLE_BYTES, sizeof h);
+    void* ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      p2p_close(c);
+      return fail(IQLHIP_EHIP, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+    }
+    c->peer_blk[r] = (char*)ptr;
+  }
+  c->p2p_attached = true;
+  c->xtimeout_ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 5000) * 100000ull;   // 100 MHz wall clock
+  c->xstep = 0;
+  HIPCHK(hipMemset(c->xstatus, 0, 2 * sizeof(unsigned long long)));
+  c->xch_mode = IQLHIP_XCH_P2P;
+  drop_graph(c);
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_xch_select(iqlhip_ctx* c, int mode) {
+  if (!c) return fail(IQLHIP_EINVAL, "NULL ctx");
+  if (mode == IQLHIP_XCH_RCCL && !c->nccl_comm) return fail(IQLHIP_EINVAL, "no RCCL communicator (iqlhip_allreduce_init)");
+  if (mode == IQLHIP_XCH_P2P && !c->p2p_attached) return fail(IQLHIP_EINVAL, "no P2P exchange (iqlhip_p2p_attach)");
+  if (mode != IQLHIP_XCH_NONE && mode != IQLHIP_XCH_RCCL && mode != IQLHIP_XCH_P2P) return fail(IQLHIP_EINVAL, "unknown exchange mode %d", mode);
+  c->xch_mode = mode;
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_xch_status(iqlhip_ctx* c, int64_t status[3], void* stream) {
+  if (!c || !status) return fail(IQLHIP_EINVAL, "NULL argument");
+  DevGuard guard(c->device);
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemcpy(h, c->xstatus, sizeof h, hipMemcpyDeviceToHost));
+  status[0] = c->xch_mode;
+  status[1] = (int64_t)h[0];
+  status[2] = (int64_t)c->xstep;
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_xch_shutdown(iqlhip_ctx* c) {
+  if (!c) return IQLHIP_OK;
+  DevGuard guard(c->device);
+  (void)hipDeviceSynchronize();
+  drop_graph(c);
+  if (c->nccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl_comm);
+  c->nccl_comm = nullptr;
+  p2p_close(c);
+  if (c->xblk) (void)hipFree(c->xblk);
+  c->xblk = nullptr;
+  c->xch_mode = IQLHIP_XCH_NONE;
+  c->world = 1;
+  c->rank = 0;
+  return IQLHIP_OK;
+}
+
+static XchParams make_xch(const iqlhip_ctx* c, bool from_hdr) {
+  XchParams x;
+  memset(&x, 0, sizeof x);
+  for (int r = 0; r < IQLHIP_MAX_WORLD; ++r)
+    x.peer_flags[r] = (unsigned long long*)c->peer_blk[std::min(r, c->world - 1)];
+  x.status = c->xstatus;
+  x.hdr = from_hdr ? c->hdr : nullptr;
+  x.xstep = c->xstep;
+  x.timeout_ticks = c->xtimeout_ticks;
+  x.rank = c->rank;
+  x.world = c->world;
+  return x;
+}
+
+// One step's launches after the batch has been staged: forward, backward and — by exchange mode — the update, or
+// flatten + all-reduce + update, or flatten + flag handshake + the update that reads every rank's buffer.
+// `k` = position inside the chunk (selects the P2P buffer together with `parity`, and the flag value hdr[XSTEP]+k+1).
+static int enqueue_step(iqlhip_ctx* c, const StepParams& p, UpdParams u, int mode, int parity, int k, bool from_hdr,
+                        hipStream_t st, hipEvent_t* ev) {
+  launch_fwd(c, p, st);
+  if (ev) HIPCHK(hipEventRecord(ev[1], st));
+  launch_bwd(c, p, st);
+  if (ev) HIPCHK(hipEventRecord(ev[2], st));
+  if (mode == IQLHIP_XCH_RCCL) {
+    launch_flatten(c, u, c->xflat, false, st);
+    NCCLCHK(g_rccl.AllReduce(c->xflat, c->xflat, (size_t)c->L.n_params + 4, RCCL_FLOAT32, RCCL_SUM, c->nccl_comm, st));
+    u.flat_grads = c->xflat;
+  } else if (mode == IQLHIP_XCH_P2P) {
+    const int buf = (parity + k) & 1;
+    launch_flatten(c, u, (float*)(c->xblk + c->xflat_off[buf]), true, st);
+    if (c->world > 1) hipLaunchKernelGGL(iql_xch_signal_wait_kernel, dim3(1), dim3(64), 0, st, make_xch(c, from_hdr), k);
+    for (int r = 0; r < IQLHIP_MAX_WORLD; ++r)
+      u.peer_flat[r] = (const float*)(c->peer_blk[std::min(r, c->world - 1)] + c->xflat_off[buf]);
+    u.n_peer = c->world;
+  }
+  launch_upd(c, u, st);
+  if (ev) HIPCHK(hipEventRecord(ev[3], st));
+  return IQLHIP_OK;
 }
 
 static int ensure_events(iqlhip_ctx* c, int n) {
@@ -521,6 +810,7 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   if (!c || !sc) return fail(IQLHIP_EINVAL, "NULL argument");
   int rc = check_batch(c, b);
   if (rc) return rc;
+  DevGuard guard(c->device);
   hipStream_t st = (hipStream_t)stream;
   const float* xb_cur = nullptr;
   rc = stage_batch(c, b, st, &xb_cur);
@@ -538,12 +828,9 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
     c->ev_used += 4;
     HIPCHK(hipEventRecord(ev[0], st));
   }
-  launch_fwd(c, p, st);
-  if (ev) HIPCHK(hipEventRecord(ev[1], st));
-  launch_bwd(c, p, st);
-  if (ev) HIPCHK(hipEventRecord(ev[2], st));
-  launch_upd(c, u, st);
-  if (ev) HIPCHK(hipEventRecord(ev[3], st));
+  rc = enqueue_step(c, p, u, c->xch_mode, (int)(c->xstep & 1ull), 0, /*from_hdr=*/false, st, ev);
+  if (rc) return rc;
+  if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += 1;
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }
@@ -553,6 +840,7 @@ extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, con
   if (!c || !sc || !grads_dev) return fail(IQLHIP_EINVAL, "NULL argument");
   int rc = check_batch(c, b);
   if (rc) return rc;
+  DevGuard guard(c->device);
   hipStream_t st = (hipStream_t)stream;
   const float* xb_cur = nullptr;
   rc = stage_batch(c, b, st, &xb_cur);
@@ -563,8 +851,7 @@ extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, con
   UpdParams u = make_upd(c, sc, b->rows, nullptr);
   launch_fwd(c, p, st);
   launch_bwd(c, p, st);
-  const int nb = (int)((c->L.n_params / 4 + 255) / 256);
-  hipLaunchKernelGGL(iql_grad_flatten_kernel, dim3(nb), dim3(256), 0, st, u, grads_dev);
+  launch_flatten(c, u, grads_dev, false, st);
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }
@@ -572,6 +859,7 @@ extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, con
 extern "C" int iqlhip_apply_update(iqlhip_ctx* c, const float* grads_dev, const iqlhip_step_scalars* sc, void* stream) {
   if (!c || !sc || !grads_dev) return fail(IQLHIP_EINVAL, "NULL argument");
   if (!c->params) return fail(IQLHIP_ENOTBOUND, "iqlhip_bind has not been called");
+  DevGuard guard(c->device);
   UpdParams u = make_upd(c, sc, 1, grads_dev);
   launch_upd(c, u, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
@@ -609,87 +897,170 @@ extern "C" int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, ui
   return IQLHIP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The multi-step driver.  A call of n steps = floor(n / GRAPH_STEPS) replays of ONE captured chunk graph +
+// n % GRAPH_STEPS steps launched directly; both run the same launch sequence (enqueue_chunk) and read their
+// per-launch values (buffer size, RNG position, scalar table slice, ring position, exchange step) from device words
+// that iql_chunk_setup_kernel rewrites in front of every chunk.
+static int enqueue_chunk(iqlhip_ctx* c, hipStream_t st, const float* rows_dev, int64_t size_unused, int B, int K,
+                         float inv_batch, int mode, int parity) {
+  (void)size_unused;
+  {
+    const long long n = (long long)K * B;
+    const int nb = (int)std::min<long long>((n / 2 + 255) / 256 + 1, 1024);
+    hipLaunchKernelGGL(iql_draw_indices_kernel, dim3(nb), dim3(256), 0, st, c->idx_chunk, n, 0ll, 0ull, 0ull,
+                       (const unsigned long long*)c->hdr);
+  }
+  // rows of step 0 (standalone gather); step k+1's are staged by the idle blocks of forward k into the other of
+  // the two staging buffers (forward k and backward k read buffer k & 1)
+  launch_gather(c, rows_dev, c->idx_chunk, B, st);
+  if (c->drop_p > 0.f) launch_dropmask(c, 0, 0, c->hdr, 0, st);   // keep-bits of step 0 (seed / first step from hdr)
+  iqlhip_step_scalars sc0;
+  memset(&sc0, 0, sizeof sc0);
+  sc0.inv_batch = inv_batch;
+  for (int k = 0; k < K; ++k) {
+    StepParams p = make_step(c, B, inv_batch);
+    p.xb = (k & 1) ? c->xb2 : c->xb;
+    UpdParams u = make_upd(c, &sc0, B, nullptr);
+    u.sched = c->sched_cur;
+    u.sched_idx = k;
+    u.loss_ring = c->loss_ring;
+    u.ring_slot = k;
+    u.ring_hdr = c->hdr;
+    if (k + 1 < K) {
+      p.g_rows = rows_dev; p.g_idx = c->idx_chunk + (long long)(k + 1) * B; p.g_n = B;
+      p.g_xb = (k & 1) ? c->xb : c->xb2;
+      if (c->drop_p > 0.f) { u.d_bits = c->drop_bits; u.d_thresh = drop_thresh(c->drop_p); u.d_k = k + 1; }
+    }
+    int rc = enqueue_step(c, p, u, mode, parity, k, /*from_hdr=*/true, st, nullptr);
+    if (rc) return rc;
+  }
+  return IQLHIP_OK;
+}
+
+static int chunk_graph(iqlhip_ctx* c, const GraphKey& key, hipGraphExec_t* out, iqlhip_ctx::CachedGraph** slot) {
+  for (auto& g : c->graphs)
+    if (g.key == key) { g.stamp = ++c->graph_clock; *out = g.exec; if (slot) *slot = &g; return IQLHIP_OK; }
+  if (c->graphs.size() >= 6) {   // evict the least recently used — after its last replay has finished
+    size_t lru = 0;
+    for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].stamp < c->graphs[lru].stamp) lru = i;
+    if (c->graphs[lru].last) HIPCHK(hipStreamSynchronize(c->graphs[lru].last));
+    (void)hipGraphExecDestroy(c->graphs[lru].exec);
+    (void)hipGraphDestroy(c->graphs[lru].graph);
+    c->graphs.erase(c->graphs.begin() + lru);
+  }
+  hipStream_t cs = c->cap_stream;
+  // (relaxed: a collective library may make calls during capture that the stricter modes forbid)
+  HIPCHK(hipStreamBeginCapture(cs, key.xch == IQLHIP_XCH_RCCL ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+  int rc = enqueue_chunk(c, cs, key.rows, 0, key.B, GRAPH_STEPS, key.inv_batch, key.xch, key.parity);
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(cs, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return fail(IQLHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t gexec = nullptr;
+  HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+  c->graphs.push_back({key, graph, gexec, ++c->graph_clock, nullptr});
+  *out = gexec;
+  if (slot) *slot = &c->graphs.back();
+  return IQLHIP_OK;
+}
+
+static int check_train_args(const iqlhip_ctx* c, const float* rows_dev, int64_t ld, int32_t B) {
+  if (!c || !rows_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (!c->params) return fail(IQLHIP_ENOTBOUND, "iqlhip_bind has not been called");
+  if (B < 1 || B > c->dims.max_batch) return fail(IQLHIP_EINVAL, "batch_rows outside [1,max_batch]");
+  if (ld != c->row_ld) return fail(IQLHIP_EINVAL, "row stride must be iqlhip_row_stride(S,A)=%lld", (long long)c->row_ld);
+  if (((uintptr_t)rows_dev) & 15) return fail(IQLHIP_EINVAL, "packed rows must be 16-byte aligned");
+  return IQLHIP_OK;
+}
+
+static GraphKey make_key(const iqlhip_ctx* c, const float* rows_dev, int64_t ld, int32_t B, float inv_batch, int parity) {
+  GraphKey key;
+  key.rows = rows_dev; key.ld = ld; key.B = B; key.params = c->params; key.drop_p = c->drop_p;
+  key.inv_batch = inv_batch; key.xch = c->xch_mode;
+  key.parity = (c->xch_mode == IQLHIP_XCH_P2P) ? parity : 0;
+  return key;
+}
+
+extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, int64_t ld, int32_t B, float inv_batch) {
+  int rc = check_train_args(c, rows_dev, ld, B);
+  if (rc) return rc;
+  DevGuard guard(c->device);
+  for (int parity = 0; parity < ((c->xch_mode == IQLHIP_XCH_P2P) ? 2 : 1); ++parity) {
+    hipGraphExec_t gexec = nullptr;
+    rc = chunk_graph(c, make_key(c, rows_dev, ld, B, inv_batch, parity), &gexec, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipGraphUpload(gexec, c->cap_stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->cap_stream));
+  return IQLHIP_OK;
+}
+
 extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t ld, int64_t size, int32_t B,
                                   const iqlhip_step_scalars* sc, int32_t K, uint64_t seed, uint64_t stream_offset,
                                   void* stream) {
-  if (!c || !rows_dev || !sc) return fail(IQLHIP_EINVAL, "NULL argument");
-  if (!c->params) return fail(IQLHIP_ENOTBOUND, "iqlhip_bind has not been called");
+  if (!sc) return fail(IQLHIP_EINVAL, "NULL argument");
+  int rc = check_train_args(c, rows_dev, ld, B);
+  if (rc) return rc;
   if (K < 1 || K > c->k_max) return fail(IQLHIP_EINVAL, "n_steps outside [1,%d]", c->k_max);
-  if (B < 1 || B > c->dims.max_batch) return fail(IQLHIP_EINVAL, "batch_rows outside [1,max_batch]");
   if (size < 1) return fail(IQLHIP_EINVAL, "empty buffer");
-  const int S = c->dims.state_dim, A = c->dims.action_dim;
-  if (ld != c->row_ld) return fail(IQLHIP_EINVAL, "row stride must be iqlhip_row_stride(S,A)=%lld", (long long)c->row_ld);
-  if (((uintptr_t)rows_dev) & 15) return fail(IQLHIP_EINVAL, "packed rows must be 16-byte aligned");
+  DevGuard guard(c->device);
   hipStream_t st = (hipStream_t)stream;
-  GraphKey key;
-  key.rows = rows_dev; key.ld = ld; key.B = B; key.K = K; key.params = c->params; key.drop_p = c->drop_p;
-  hipGraphExec_t gexec = nullptr;
-  for (auto& g : c->graphs)
-    if (g.key == key) { gexec = g.exec; g.stamp = ++c->graph_clock; }
-  if (!gexec) {
-    if (c->graphs.size() >= 4) {   // evict the least recently used
-      size_t lru = 0;
-      for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].stamp < c->graphs[lru].stamp) lru = i;
-      (void)hipGraphExecDestroy(c->graphs[lru].exec);
-      (void)hipGraphDestroy(c->graphs[lru].graph);
-      c->graphs.erase(c->graphs.begin() + lru);
-    }
-    hipStream_t cs = c->cap_stream;
-    HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    {
-      const long long n = (long long)K * B;
-      const int nb = (int)std::min<long long>((n / 2 + 255) / 256 + 1, 1024);
-      hipLaunchKernelGGL(iql_draw_indices_kernel, dim3(nb), dim3(256), 0, cs, c->idx_chunk, n, (long long)size,
-                         0ull, 0ull, (const unsigned long long*)c->hdr);
-    }
-    // rows of step 0 (standalone gather); step k+1's are staged by the idle blocks of forward k into the other of
-    // the two staging buffers (forward k and backward k read buffer k & 1)
-    launch_gather(c, rows_dev, c->idx_chunk, B, cs);
-    if (c->drop_p > 0.f) launch_dropmask(c, 0, 0, c->hdr, 0, cs);   // keep-bits of step 0 (seed/step0 from hdr)
-    for (int k = 0; k < K; ++k) {
-      StepParams p = make_step(c, B, sc[0].inv_batch);
-      p.xb = (k & 1) ? c->xb2 : c->xb;
-      UpdParams u = make_upd(c, &sc[0], B, nullptr);
-      u.sched = c->sched;
-      u.sched_idx = k;
-      u.loss_ring = c->loss_ring;
-      u.ring_slot = k;
-      if (k + 1 < K) {
-        p.g_rows = rows_dev; p.g_idx = c->idx_chunk + (long long)(k + 1) * B; p.g_n = B;
-        p.g_xb = (k & 1) ? c->xb : c->xb2;
-        if (c->drop_p > 0.f) { u.d_bits = c->drop_bits; u.d_thresh = drop_thresh(c->drop_p); u.d_k = k + 1; }
-      }
-      launch_fwd(c, p, cs);
-      launch_bwd(c, p, cs);
-      launch_upd(c, u, cs);
-    }
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipStreamEndCapture(cs, &graph);
-    if (e != hipSuccess) return fail(IQLHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
-    c->graphs.push_back({key, graph, gexec, ++c->graph_clock});
-  }
-  unsigned long long hdr[4] = {(unsigned long long)size, (unsigned long long)seed, (unsigned long long)stream_offset,
-                               c->drop_step};
-  c->drop_step += (unsigned long long)K;
-  HIPCHK(hipMemcpyAsync(c->hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(c->sched, sc, (size_t)K * sizeof(iqlhip_step_scalars), hipMemcpyHostToDevice, st));
-  hipEvent_t* ev = nullptr;
+  // the call's scalar table goes into a pinned, host-mapped slot that the chunk setup kernels read in place; a slot is
+  // reused only after the call that used it has drained (event), so the caller's array is free on return
+  const int slot = c->sched_slot;
+  c->sched_slot = (c->sched_slot + 1) & 3;
+  HIPCHK(hipEventSynchronize(c->sched_done[slot]));
+  memcpy(c->sched_pin[slot], sc, (size_t)K * sizeof(iqlhip_step_scalars));
+  const float inv_batch = sc[0].inv_batch;
+  const unsigned long long per_step = (unsigned long long)((B + 1) / 2);      // Philox counters one step's draw uses
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (c->timing) {
-    int rc = ensure_events(c, c->ev_used + 2);
+    rc = ensure_events(c, c->ev_used + 2);
     if (rc) return rc;
-    ev = &c->ev[c->ev_used];
-    HIPCHK(hipEventRecord(ev[0], st));
+    ev0 = c->ev[c->ev_used]; ev1 = c->ev[c->ev_used + 1];
+    HIPCHK(hipEventRecord(ev0, st));
   }
-  HIPCHK(hipGraphLaunch(gexec, st));
-  if (ev) {
-    HIPCHK(hipEventRecord(ev[1], st));
-    HIPCHK(hipEventSynchronize(ev[1]));
+  int done = 0;
+  while (done < K) {
+    const int n = std::min(GRAPH_STEPS, K - done);
+    ChunkHdr h;
+    memset(&h, 0, sizeof h);
+    h.w[HDR_SIZE] = (unsigned long long)size;
+    h.w[HDR_SEED] = (unsigned long long)seed;
+    h.w[HDR_OFFSET] = (unsigned long long)stream_offset + (unsigned long long)done * per_step;
+    h.w[HDR_DROP_STEP] = c->drop_step;
+    h.w[HDR_DROP_SEED] = c->drop_seed;
+    h.w[HDR_BASE] = (unsigned long long)done;
+    h.w[HDR_XSTEP] = c->xstep;
+    hipLaunchKernelGGL(iql_chunk_setup_kernel, dim3(1), dim3(256), 0, st, c->hdr, h, c->sched_cur,
+                       (const iqlhip_step_scalars*)(c->sched_pin[slot] + done), n);
+    const int parity = (int)(c->xstep & 1ull);
+    if (n == GRAPH_STEPS) {
+      hipGraphExec_t gexec = nullptr;
+      iqlhip_ctx::CachedGraph* cg = nullptr;
+      rc = chunk_graph(c, make_key(c, rows_dev, ld, B, inv_batch, parity), &gexec, &cg);
+      if (rc) return rc;
+      HIPCHK(hipGraphLaunch(gexec, st));
+      cg->last = st;
+    } else {
+      rc = enqueue_chunk(c, st, rows_dev, size, B, n, inv_batch, c->xch_mode, parity);
+      if (rc) return rc;
+    }
+    c->drop_step += (unsigned long long)n;
+    if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += (unsigned long long)n;
+    done += n;
+  }
+  HIPCHK(hipEventRecord(c->sched_done[slot], st));
+  if (ev0) {
+    HIPCHK(hipEventRecord(ev1, st));
+    HIPCHK(hipEventSynchronize(ev1));
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
-    c->t_acc[3] += ms * 1e3f;   // total per chunk; per-step = /K done by the caller
+    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    c->t_acc[3] += ms * 1e3f;   // total per call; per-step = /K done by the caller
     c->t_n += 1;
   }
+  HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }
 

@@ -1450,6 +1450,11 @@ struct UpdParams {
   const float* slab_b;
   long long slab_b_off[4];
   const float* flat_grads;  // when non-null: gradient already summed (DP path), n_params + 4 words
+  // direct-read exchange (xGMI peer-to-peer): n_peer > 0 -> the gradient is the sum, in rank order, of the n_peer flat
+  // buffers peer_flat[0..n_peer) (this rank's own buffer included; the others are IPC-mapped peer memory, read with
+  // system-scope loads).  Every rank forms the same sum in the same order: replicas stay bitwise equal.
+  const float* peer_flat[IQLHIP_MAX_WORLD];
+  int n_peer;
   float* loss_parts;
   float* losses;            // [4]
   float* loss_ring;         // nullable
@@ -1465,7 +1470,15 @@ struct UpdParams {
   unsigned d_thresh;
   const unsigned long long* d_hdr;
   int d_k;
+  // chunk replay: the loss-ring slot of this launch is ring_slot + ring_hdr[HDR_BASE] (the chunk's first step inside
+  // the call; a captured chunk is replayed at different positions of the ring); null = ring_slot as given
+  const unsigned long long* ring_hdr;
 };
+
+// Device words a chunk of steps (captured in a hipGraph or launched eagerly) reads its per-launch values from: kernel
+// arguments of a captured graph are frozen, these words are rewritten by iql_chunk_setup_kernel before every replay.
+enum { HDR_SIZE = 0, HDR_SEED = 1, HDR_OFFSET = 2, HDR_DROP_STEP = 3, HDR_DROP_SEED = 4, HDR_BASE = 5, HDR_XSTEP = 6, HDR_WORDS = 8 };
+struct ChunkHdr { unsigned long long w[HDR_WORDS]; };
 
 __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
   int n = 0;
@@ -1549,8 +1562,21 @@ __device__ __forceinline__ void dropmask_words(unsigned* bits, int n_words, unsi
 __global__ __launch_bounds__(256) void iql_dropmask_kernel(unsigned* bits, int n_words, unsigned thresh,
                                                            unsigned long long seed, unsigned long long step,
                                                            const unsigned long long* hdr, int k) {
-  if (hdr) { seed = hdr[1] ^ 0x5EEDD120ull; step = hdr[3] + (unsigned long long)k; }
+  if (hdr) { seed = hdr[HDR_DROP_SEED]; step = hdr[HDR_DROP_STEP] + (unsigned long long)k; }
   dropmask_words(bits, n_words, thresh, seed, step, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+// Per-launch values of a chunk (see ChunkHdr) + the chunk's slice of the per-step scalar table: sched_src is the
+// library's pinned, host-mapped copy of the caller's table (read over PCIe: <= 64 x 48 B), sched_cur the fixed device
+// array the chunk's update kernels index with their frozen step number.
+__global__ __launch_bounds__(256) void iql_chunk_setup_kernel(unsigned long long* hdr, ChunkHdr h,
+                                                              iqlhip_step_scalars* sched_cur,
+                                                              const iqlhip_step_scalars* sched_src, int n) {
+  if (threadIdx.x < HDR_WORDS) hdr[threadIdx.x] = h.w[threadIdx.x];
+  const float* s = (const float*)sched_src;
+  float* d = (float*)sched_cur;
+  const int words = n * (int)(sizeof(iqlhip_step_scalars) / sizeof(float));
+  for (int i = threadIdx.x; i < words; i += 256) d[i] = s[i];
 }
 
 __global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long long ld, const long long* idx,
@@ -1558,36 +1584,94 @@ __global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long
   gather_rows_flat(rows, ld, idx, xb, n, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-// Writes the summed flat gradient (+ tail: value, q, actor loss contributions, spare) for the DP all-reduce.
+// 16-byte accesses at SYSTEM scope (sc0 sc1): the load misses every cache level that is not coherent with another
+// device's writes (IPC-mapped peer memory over xGMI), the store is written through to memory.  There is no 16-byte
+// atomic, so these are the instructions the memory model uses for system-scope relaxed accesses, issued by hand.
+__device__ __forceinline__ f32x4 load16_sys(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void store16_sys(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Direct-read gradient exchange between the ranks of one node (one process per GPU, buffers mapped with hipIpc):
+// after its flatten kernel (whose stores are complete at the kernel boundary) rank r stores the step number into ITS
+// slot of every peer's flag block, then waits until every peer's slot of its OWN flag block has reached that number;
+// the update kernel that follows reads all ranks' flat gradients.  Buffers alternate by step parity: rank r rewrites
+// buffer b two steps later, i.e. after it has seen every peer's signal of the step in between, which a peer only
+// sends after its own update (its reads of buffer b) has finished.
+// The wait is bounded: a peer that never arrives (crashed rank) makes the lane give up after `timeout_ticks` of the
+// 100 MHz wall clock, record the step in status[0] (sticky: later waits return at once) and let the stream drain —
+// the host reports it (iqlhip_xch_status), the grid never hangs.
+struct XchParams {
+  unsigned long long* peer_flags[IQLHIP_MAX_WORLD];   // base of every rank's flag block [world][16] (own = local)
+  unsigned long long* status;                          // [0] first timed-out step (0 = none), [1] polls (diagnostic)
+  const unsigned long long* hdr;                       // HDR_XSTEP: steps exchanged before this chunk (chunk replay) ...
+  unsigned long long xstep;                            // ... or, hdr == null, the same number as a kernel argument
+  unsigned long long timeout_ticks;
+  int rank, world;
+};
+__global__ __launch_bounds__(64) void iql_xch_signal_wait_kernel(XchParams x, int k) {
+  const int t = threadIdx.x;
+  const unsigned long long v = (x.hdr ? x.hdr[HDR_XSTEP] : x.xstep) + (unsigned long long)k + 1ull;
+  if (t < x.world && t != x.rank) {
+    // release at system scope, drained, THEN the flag (the explicit wait: hipcc may drop the one that belongs to the
+    // fence when its own scoreboard is empty, and the flag must not overtake the write-back)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    wait_vm0();
+    __hip_atomic_store(x.peer_flags[t] + 16 * x.rank, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* mine = x.peer_flags[x.rank] + 16 * t;
+    if (__hip_atomic_load(x.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+      const unsigned long long t0 = wall_clock64();
+      unsigned long long polls = 0;
+      while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
+        __builtin_amdgcn_s_sleep(4);
+        if (((++polls) & 63ull) == 0ull && wall_clock64() - t0 > x.timeout_ticks) {
+          __hip_atomic_store(x.status, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+  }
+}
+
+// Writes the summed flat gradient (+ tail: value, q, actor loss contributions, spare) for the DP exchange.
+// SYS: write-through system-scope stores (the buffer is read by peer GPUs).
+template <bool SYS>
 __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, float* out) {
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (e < u.L.n_params) {
     const int net = net_of(u.L, e);
-    *(f32x4*)(out + e) = slab_grad(u, e, net);
+    const f32x4 gv = slab_grad(u, e, net);
+    if (SYS) store16_sys(out + e, gv);
+    else *(f32x4*)(out + e) = gv;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float s[4];
     loss_words(u, s);
     const float ib = u.sc.inv_batch;
-    out[u.L.n_params + 0] = s[0] * ib;
-    out[u.L.n_params + 1] = (s[1] * ib + s[2] * ib) * 0.5f;
-    out[u.L.n_params + 2] = s[3] * ib;
-    out[u.L.n_params + 3] = 0.f;
+    const f32x4 tail = (f32x4){s[0] * ib, (s[1] * ib + s[2] * ib) * 0.5f, s[3] * ib, 0.f};
+    if (SYS) store16_sys(out + u.L.n_params, tail);
+    else *(f32x4*)(out + u.L.n_params) = tail;
   }
 }
 
 // FROM_TABLE: the per-step scalars come from the device table u.sched[u.sched_idx] (hipGraph replay: kernel
 // arguments are frozen, the table is not); otherwise from the kernel argument u.sc.  Two instantiations
 // rather than a run-time pointer select, which would turn every access into a flat load.
-template <bool FROM_TABLE>
+// PEER: the direct-read exchange variant (gradient = rank-ordered sum over UpdParams::peer_flat).
+template <bool FROM_TABLE, bool PEER>
 __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
   if ((int)blockIdx.x >= u.n_upd_blocks) {
     // extra blocks: the next step's dropout keep-bits while the optimizer blocks run (the next step's ROWS are
     // staged by the forward kernel's idle blocks, see StepParams::g_idx)
     const int mb = (int)blockIdx.x - u.n_upd_blocks;
     const int nmb = (int)gridDim.x - u.n_upd_blocks;
-    dropmask_words(u.d_bits, u.d_n_words, u.d_thresh, u.d_hdr[1] ^ 0x5EEDD120ull,
-                   u.d_hdr[3] + (unsigned long long)u.d_k, mb * 256 + threadIdx.x, nmb * 256);
+    dropmask_words(u.d_bits, u.d_n_words, u.d_thresh, u.d_hdr[HDR_DROP_SEED],
+                   u.d_hdr[HDR_DROP_STEP] + (unsigned long long)u.d_k, mb * 256 + threadIdx.x, nmb * 256);
     return;
   }
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -1602,7 +1686,16 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (is_q) t = *(f32x4*)tp;
     f32x4 gr;
-    if (u.flat_grads) gr = *(const f32x4*)(u.flat_grads + e);
+    if (PEER) {
+      // all ranks' contributions requested together (one fabric round trip), summed in rank order
+      f32x4 pv[IQLHIP_MAX_WORLD];
+#pragma unroll
+      for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) pv[r] = load16_sys(u.peer_flat[min(r, u.n_peer - 1)] + e);
+      wait_vm0();
+      gr = pv[0];
+#pragma unroll
+      for (int r = 1; r < IQLHIP_MAX_WORLD; ++r) if (r < u.n_peer) gr += pv[r];
+    } else if (u.flat_grads) gr = *(const f32x4*)(u.flat_grads + e);
     else gr = slab_grad(u, e, net);
     const int grp = (net == IQLHIP_NET_V) ? 0 : ((net == IQLHIP_NET_PI) ? 2 : 1);
     // (copy by value: a pointer that may address either the kernarg segment or global memory would make
@@ -1633,7 +1726,16 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float l[3];
-    if (u.flat_grads) {
+    if (PEER) {
+      f32x4 t = load16_sys(u.peer_flat[0] + u.L.n_params);
+      wait_vm0();
+      for (int r = 1; r < u.n_peer; ++r) {
+        const f32x4 tr = load16_sys(u.peer_flat[r] + u.L.n_params);
+        wait_vm0();
+        t += tr;
+      }
+      l[0] = t[0]; l[1] = t[1]; l[2] = t[2];
+    } else if (u.flat_grads) {
       l[0] = u.flat_grads[u.L.n_params + 0];
       l[1] = u.flat_grads[u.L.n_params + 1];
       l[2] = u.flat_grads[u.L.n_params + 2];
@@ -1647,7 +1749,8 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     }
     u.losses[0] = l[0]; u.losses[1] = l[1]; u.losses[2] = l[2];
     if (u.loss_ring) {
-      float* rr = u.loss_ring + 4 * (long long)u.ring_slot;
+      const long long slot = (long long)u.ring_slot + (u.ring_hdr ? (long long)u.ring_hdr[HDR_BASE] : 0ll);
+      float* rr = u.loss_ring + 4 * slot;
       rr[0] = l[0]; rr[1] = l[1]; rr[2] = l[2]; rr[3] = 0.f;
     }
   }
@@ -1757,7 +1860,7 @@ __global__ void iql_rows_gather_kernel(const float* rows, long long ld, int S, i
 // with new values.
 __global__ void iql_draw_indices_kernel(long long* idx, long long n, long long size, unsigned long long seed,
                                         unsigned long long offset, const unsigned long long* hdr) {
-  if (hdr) { size = (long long)hdr[0]; seed = hdr[1]; offset = hdr[2]; }
+  if (hdr) { size = (long long)hdr[HDR_SIZE]; seed = hdr[HDR_SEED]; offset = hdr[HDR_OFFSET]; }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n + 1) / 2;
        i += (long long)gridDim.x * blockDim.x) {
     const unsigned long long ctr = offset + (unsigned long long)i;

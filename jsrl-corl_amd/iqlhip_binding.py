@@ -15,6 +15,11 @@ LIB_PATH = os.environ.get("IQLHIP_LIB", os.path.join(_HERE, "libiqlhip.so"))  # 
 
 IQLHIP_HIDDEN = 256
 IQLHIP_ACT_ROWS = 4096      # rows per iqlhip_actor_forward call (include/iqlhip.h)
+IQLHIP_MAX_WORLD = 8
+IQLHIP_GRAPH_STEPS = 64
+IQLHIP_UNIQUE_ID_BYTES = 128
+IQLHIP_IPC_HANDLE_BYTES = 64
+XCH_NONE, XCH_RCCL, XCH_P2P = 0, 1, 2
 NET_V, NET_Q1, NET_Q2, NET_PI = 0, 1, 2, 3
 POLICY_GAUSSIAN, POLICY_DETERMINISTIC = 0, 1
 
@@ -76,6 +81,14 @@ SYMBOLS = [
     ("iqlhip_grad_words", C.c_int64, [C.c_void_p]),
     ("iqlhip_train_steps", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                      C.POINTER(StepScalars), C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p]),
+    ("iqlhip_train_steps_prepare", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float]),
+    ("iqlhip_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("iqlhip_allreduce_init", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("iqlhip_p2p_export", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("iqlhip_p2p_attach", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("iqlhip_xch_select", C.c_int, [C.c_void_p, C.c_int]),
+    ("iqlhip_xch_status", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    ("iqlhip_xch_shutdown", C.c_int, [C.c_void_p]),
     ("iqlhip_read_losses", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
     ("iqlhip_read_loss_ring", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_void_p]),
     ("iqlhip_row_stride", C.c_int64, [C.c_int32, C.c_int32]),

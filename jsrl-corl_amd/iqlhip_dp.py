@@ -47,3 +47,12 @@ def broadcast_state(tensors, group: Optional[dist.ProcessGroup] = None, src: int
     """Make rank `src`'s parameters / moments / target the common starting point."""
     for t in tensors:
         dist.broadcast(t, src=src, group=group)
+
+
+def broadcast_state_host(tensors, group: Optional[dist.ProcessGroup] = None, src: int = 0) -> None:
+    """The same through host copies, for process groups whose backend cannot move device tensors (gloo rehearsals
+    of the peer-to-peer exchange with several ranks on one GPU)."""
+    for t in tensors:
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)

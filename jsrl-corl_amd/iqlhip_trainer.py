@@ -83,6 +83,9 @@ class ImplicitQLearning:
         # data-parallel state (set by enable_data_parallel)
         self._dp_group = None
         self._dp_world = 1
+        self._dp_rank = 0
+        self._dp_exchange = None      # None | "rccl" | "p2p" (in-library) | "torch" (torch.distributed.all_reduce)
+        self._table_cache = None
 
         self._ctx = None
         self._max_batch = 0
@@ -139,11 +142,15 @@ class ImplicitQLearning:
         dev = torch.device(self.device)
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
+        if not 1 <= max_batch <= 16384:
+            raise ValueError(f"iqlhip: batch of {max_batch} rows is outside the library's range [1, 16384]")
         L = hb.arena_layout(S, A, gaussian, max_batch)
         old = None
         if self._ctx is not None:
+            if self._dp_world > 1:
+                raise RuntimeError("iqlhip: the batch size cannot grow after enable_data_parallel(); construct the "
+                                   "trainer's first step (or call reserve_batch) with the largest batch first")
             old = (self._params_arena, self._target_arena, self._m_arena, self._v_arena)
-            self._release()
         self._S, self._A, self._gaussian, self._layout = S, A, gaussian, L
         if old is None:
             self._params_arena = torch.zeros(L.n_params, dtype=torch.float32, device=dev)
@@ -160,7 +167,9 @@ class ImplicitQLearning:
         h = self._hyper_struct()
         ctx = C.c_void_p()
         hb.check(hb.lib().iqlhip_create(C.byref(d), C.byref(h), dev.index, C.byref(ctx)))
+        self._release()                 # the previous (smaller) context, only now that the new one exists
         self._ctx = ctx
+        self._table_cache = None
         self._hyper_sent = self._hyper_tuple()
         self._dropout_sent = 0.0
         self._max_batch = max_batch
@@ -291,6 +300,12 @@ class ImplicitQLearning:
                 "iqlhip: ImplicitQLearning.train needs a GPU device (device='cuda'); there is no CPU "
                 "implementation of the step in this package")
 
+    def reserve_batch(self, rows: int) -> None:
+        """Size the library's scratch for batches of up to `rows` rows now (otherwise it grows on first use)."""
+        self._require_gpu()
+        if rows > self._max_batch:
+            self._attach(max_batch=(rows + 255) // 256 * 256)
+
     def _prepare(self, rows: int) -> None:
         self._require_gpu()
         if rows > self._max_batch:
@@ -302,7 +317,7 @@ class ImplicitQLearning:
         # actor dropout follows the module's mode, like nn.Dropout (active in train(), off in eval())
         p_eff = self._actor_dropout_p() if self.actor.training else 0.0
         if p_eff != self._dropout_sent:
-            rank = torch.distributed.get_rank(self._dp_group) if self._dp_world > 1 else 0
+            rank = self._dp_rank if self._dp_world > 1 else 0
             hb.check(hb.lib().iqlhip_set_dropout(self._ctx, p_eff, dp.rank_seed(torch.initial_seed(), rank)))
             self._dropout_sent = p_eff
 
@@ -361,13 +376,18 @@ class ImplicitQLearning:
             self._adam_t[g] += 1
         sc = hb.StepScalars()
         lib = hb.lib()
-        if self._dp_world > 1:
+        if self._dp_world > 1 and self._dp_exchange == "torch":
+            # the collective issued by torch.distributed between the two halves of the step (two library calls)
             self._fill_scalars(sc, self._adam_t, self._current_lrs(), dp.inv_batch(B, self._dp_world))
             flat = self._dp_flat()
             hb.check(lib.iqlhip_forward_backward(self._ctx, C.byref(b), C.byref(sc), flat.data_ptr(), self._stream()))
             dp.reduce_and_update(
                 flat, lambda f: hb.check(lib.iqlhip_apply_update(self._ctx, f.data_ptr(), C.byref(sc), self._stream())),
                 self._dp_group)
+        elif self._dp_exchange is not None:
+            # in-library exchange (RCCL all-reduce or direct peer reads) inside iqlhip_step
+            self._fill_scalars(sc, self._adam_t, self._current_lrs(), dp.inv_batch(B, self._dp_world))
+            hb.check(lib.iqlhip_step(self._ctx, C.byref(b), C.byref(sc), self._stream()))
         else:
             self._fill_scalars(sc, self._adam_t, self._current_lrs(), 1.0 / B)
             hb.check(lib.iqlhip_step(self._ctx, C.byref(b), C.byref(sc), self._stream()))
@@ -388,25 +408,30 @@ class ImplicitQLearning:
         del keep
         return log
 
-    def _advance_schedule(self, k: int) -> np.ndarray:
-        """Actor learning rates USED by the next k steps; advances the CosineAnnealingLR object
-        by k steps.  Same float64 recursion as torch's CosineAnnealingLR.get_lr (eta_min = 0),
-        run as a plain loop instead of k scheduler.step() calls (~15 us each)."""
+    def _schedule_state(self):
+        sch = self.actor_lr_schedule
+        lr = float(self.actor_optimizer.param_groups[0]["lr"])
+        if sch is None:
+            return (lr, None, None)
+        return (lr, sch.last_epoch, sch._step_count)
+
+    def _peek_schedule(self, k: int):
+        """(actor learning rates USED by the next k steps, scheduler state after them) without touching the
+        CosineAnnealingLR object.  Same float64 recursion as torch's CosineAnnealingLR.get_lr (eta_min = 0), run as a
+        plain loop instead of k scheduler.step() calls (~15 us each).  None when the scheduler is in a state only
+        torch should advance."""
         lr = float(self.actor_optimizer.param_groups[0]["lr"])
         out = np.empty(k, dtype=np.float64)
         sch = self.actor_lr_schedule
         if sch is None:
             out[:] = lr
-            return out
+            return out, (lr, None, None)
         import math
         T = sch.T_max
         base = float(sch.base_lrs[0])
         eta_min = float(sch.eta_min)
         if eta_min != 0.0 or len(sch.base_lrs) != 1 or (sch._step_count == 1 and sch.last_epoch > 0):
-            for i in range(k):     # unusual scheduler state: let torch do it
-                out[i] = float(self.actor_optimizer.param_groups[0]["lr"])
-                self._step_schedule()
-            return out
+            return None
         e = sch.last_epoch
         cos, pi = math.cos, math.pi
         for i in range(k):
@@ -416,26 +441,43 @@ class ImplicitQLearning:
                 lr = lr + base * (1 - cos(pi / T)) / 2
             else:
                 lr = (1 + cos(pi * e / T)) / (1 + cos(pi * (e - 1) / T)) * lr
+        return out, (lr, e, sch._step_count + k)
+
+    def _commit_schedule(self, state) -> None:
+        lr, e, count = state
+        sch = self.actor_lr_schedule
+        if sch is None:
+            return
         sch.last_epoch = e
-        sch._step_count += k
+        sch._step_count = count
         self.actor_optimizer.param_groups[0]["lr"] = lr
         sch._last_lr = [lr]
         self.actor_optimizer._opt_called = True
+
+    def _advance_schedule(self, k: int) -> np.ndarray:
+        """Actor learning rates USED by the next k steps; advances the CosineAnnealingLR object by k steps."""
+        pk = self._peek_schedule(k)
+        if pk is None:
+            out = np.empty(k, dtype=np.float64)
+            for i in range(k):     # unusual scheduler state: let torch do it
+                out[i] = float(self.actor_optimizer.param_groups[0]["lr"])
+                self._step_schedule()
+            return out
+        out, state = pk
+        self._commit_schedule(state)
         return out
 
-    def _scalar_table(self, k: int, inv_batch: float) -> np.ndarray:
-        """[k,12] float32 rows laid out like iqlhip_step_scalars for the next k steps."""
+    def _build_table(self, k: int, inv_batch: float, adam_t: Dict[str, int], lr_pi: np.ndarray) -> np.ndarray:
+        """[k,12] float32 rows laid out like iqlhip_step_scalars for k steps after Adam step counts `adam_t`."""
         b1, b2, eps = self._adam_hyper()
-        lr_pi = self._advance_schedule(k)
         lrs = self._current_lrs()
         tab = np.empty((k, 12), dtype=np.float32)
         steps = np.arange(1, k + 1, dtype=np.float64)
         for i, g in enumerate(("v", "q", "pi")):
-            t = self._adam_t[g] + steps
+            t = adam_t[g] + steps
             lr = lr_pi if g == "pi" else lrs[g]
             tab[:, i] = lr / (1.0 - np.power(b1, t))
             tab[:, 3 + i] = np.sqrt(1.0 - np.power(b2, t))
-            self._adam_t[g] += k
         tab[:, 6] = b2
         tab[:, 7] = 1.0 - b1
         tab[:, 8] = 1.0 - b2
@@ -444,82 +486,94 @@ class ImplicitQLearning:
         tab[:, 11] = inv_batch
         return tab
 
-    def train_steps(self, replay_buffer, n_steps: int, batch_size: int, seed: int = 0,
-                    return_losses: bool = True, chunk: int = 1000) -> Optional[np.ndarray]:
-        """n_steps consecutive `sample -> train` iterations without host round trips
-        (the offline loop body, algorithms/offline/iql.py:631-635): indices are drawn on
-        the device (uniform with replacement, Philox keyed by (seed, total_it)), the
-        steps replay as one hipGraph per chunk of <= `chunk` (<= 1024), per-step Adam /
-        cosine-LR scalars are precomputed on the host.  Returns losses [n_steps,3]
-        (value, q, actor) when return_losses, else None (fully asynchronous)."""
+    def _table_key(self, k: int, inv_batch: float):
+        return (k, float(inv_batch), tuple(sorted(self._adam_t.items())), self._schedule_state(),
+                tuple(sorted(self._current_lrs().items())), self._adam_hyper())
+
+    def _scalar_table(self, k: int, inv_batch: float) -> np.ndarray:
+        """The per-step scalars of the next k steps (float64 Adam bias corrections and cosine learning rates, cast to
+        float32 once per step like torch does); advances the Adam step counts and the scheduler.  A table computed
+        ahead of time by _lookahead_table (while the GPU was busy with the previous chunk) is used when the state it
+        was computed for is still the current one."""
+        key = self._table_key(k, inv_batch)
+        cached = self._table_cache
+        self._table_cache = None
+        if cached is not None and cached[0] == key:
+            _, tab, sched_state = cached
+            self._commit_schedule(sched_state)
+        else:
+            lr_pi = self._advance_schedule(k)
+            tab = self._build_table(k, inv_batch, self._adam_t, lr_pi)
+        for g in self._adam_t:
+            self._adam_t[g] += k
+        return tab
+
+    def _lookahead_table(self, k: int, inv_batch: float) -> None:
+        """Precompute the table of the k steps AFTER the ones just launched (host work overlapped with the GPU)."""
+        pk = self._peek_schedule(k)
+        if pk is None:
+            return
+        lr_pi, sched_state = pk
+        self._table_cache = (self._table_key(k, inv_batch), self._build_table(k, inv_batch, self._adam_t, lr_pi),
+                             sched_state)
+
+    def _train_steps_args(self, replay_buffer, batch_size: int):
         self._prepare(batch_size)
-        if self._dp_world > 1:
-            raise NotImplementedError("train_steps is single-GPU; under data parallelism call train_on_buffer()")
+        if self._dp_world > 1 and self._dp_exchange == "torch":
+            raise NotImplementedError("train_steps needs an in-library exchange: enable_data_parallel(exchange='rccl'|'p2p')")
         if not getattr(replay_buffer, "_gpu", False):
             raise ValueError("train_steps needs a ReplayBuffer that lives on the GPU")
         size = replay_buffer._index_bound()
         if size < 1:
             raise ValueError("replay buffer is empty")
+        return size, dp.inv_batch(batch_size, self._dp_world)
+
+    def prepare_train_steps(self, replay_buffer, batch_size: int) -> None:
+        """Capture and upload the hipGraph chunk train_steps replays for this buffer / batch size now, so that no later
+        train_steps call pays for it (it is captured lazily otherwise, by the first call of >= 64 steps)."""
+        _, inv_batch = self._train_steps_args(replay_buffer, batch_size)
+        hb.check(hb.lib().iqlhip_train_steps_prepare(self._ctx, replay_buffer._rows.data_ptr(), replay_buffer._ld,
+                                                      batch_size, inv_batch))
+
+    def train_steps(self, replay_buffer, n_steps: int, batch_size: int, seed: int = 0,
+                    return_losses: bool = True, chunk: int = K_MAX) -> Optional[np.ndarray]:
+        """n_steps consecutive `sample -> train` iterations without host round trips
+        (the offline loop body, algorithms/offline/iql.py:631-635): indices are drawn on
+        the device (uniform with replacement, Philox keyed by (seed, total_it)); the library
+        replays ONE captured 64-step hipGraph chunk as often as it fits and launches the
+        remaining steps directly, so the cost per step does not depend on n_steps; per-step
+        Adam / cosine-LR scalars are precomputed on the host (the next call's while the GPU
+        runs this one's).  Under data parallelism every rank draws its own rows (rank-offset
+        stream) and the gradient exchange runs inside the same stream / graph.  Returns losses
+        [n_steps,3] (value, q, actor) when return_losses, else None (fully asynchronous)."""
+        size, inv_batch = self._train_steps_args(replay_buffer, batch_size)
         chunk = max(1, min(int(chunk), K_MAX))
         lib = hb.lib()
+        rank = self._dp_rank if self._dp_world > 1 else 0
+        seed = dp.rank_seed(seed, rank)
         losses = np.empty((n_steps, 3), dtype=np.float32) if return_losses else None
+        rows_ptr, ld, stream = replay_buffer._rows.data_ptr(), replay_buffer._ld, self._stream()
         done = 0
         while done < n_steps:
             k = min(chunk, n_steps - done)
-            tab = self._scalar_table(k, 1.0 / batch_size)
+            tab = self._scalar_table(k, inv_batch)
             hb.check(lib.iqlhip_train_steps(
-                self._ctx, replay_buffer._rows.data_ptr(), replay_buffer._ld, size, batch_size,
+                self._ctx, rows_ptr, ld, size, batch_size,
                 tab.ctypes.data_as(C.POINTER(hb.StepScalars)), k,
-                int(seed) & 0xFFFFFFFFFFFFFFFF, int(self.total_it) * ((batch_size + 1) // 2), self._stream()))
+                seed, int(self.total_it) * ((batch_size + 1) // 2), stream))
             self.total_it += k
+            done += k
+            # the GPU is busy with these k steps: compute the scalars of the next k now
+            self._lookahead_table(min(chunk, n_steps - done) if done < n_steps else k, inv_batch)
             if return_losses:
                 buf = (C.c_float * (3 * k))()
-                hb.check(lib.iqlhip_read_loss_ring(self._ctx, buf, k, self._stream()))
-                losses[done: done + k] = np.frombuffer(buf, dtype=np.float32).reshape(k, 3)
-            done += k
+                hb.check(lib.iqlhip_read_loss_ring(self._ctx, buf, k, stream))
+                losses[done - k: done] = np.frombuffer(buf, dtype=np.float32).reshape(k, 3)
         return losses
 
     def train_steps_dp(self, replay_buffer, n_steps: int, batch_size: int, seed: int = 0) -> None:
-        """n_steps data-parallel steps without host syncs: every rank draws its own rows on the
-        device (one draw per chunk, rank-offset Philox stream), then per step forward+backward →
-        all_reduce(SUM) of the flat gradient over RCCL → fused Adam/Polyak (iqlhip_dp.py).  The Adam /
-        cosine-LR scalars of the whole chunk are precomputed; the loop body is three calls."""
-        self._prepare(batch_size)
-        if not getattr(replay_buffer, "_gpu", False):
-            raise ValueError("train_steps_dp needs a ReplayBuffer that lives on the GPU")
-        size = replay_buffer._index_bound()
-        lib = hb.lib()
-        world = self._dp_world
-        rank = torch.distributed.get_rank(self._dp_group) if world > 1 else 0
-        S, A = self._S, self._A
-        base, ld = replay_buffer._rows.data_ptr(), replay_buffer._ld
-        flat = self._dp_flat()
-        fptr = flat.data_ptr()
-        stream = self._stream()
-        done = 0
-        while done < n_steps:
-            k = min(1000, n_steps - done)
-            idx = getattr(self, "_idx_chunk", None)
-            if idx is None or idx.numel() < k * batch_size:
-                idx = torch.empty(1000 * batch_size, dtype=torch.int64, device=self._dev)
-                self._idx_chunk = idx
-            hb.check(lib.iqlhip_draw_indices(idx.data_ptr(), k * batch_size, size, dp.rank_seed(seed, rank),
-                                             int(self.total_it) * ((batch_size + 1) // 2), stream))
-            tab = self._scalar_table(k, dp.inv_batch(batch_size, world))
-            rows = tab.ctypes.data
-            b = hb.Batch(base, base + 4 * S, base + 4 * (2 * S + A), base + 4 * (S + A), base + 4 * (2 * S + A + 1),
-                         ld, ld, ld, ld, ld, idx.data_ptr(), batch_size)
-            bref = C.byref(b)
-            ip = idx.data_ptr()
-            for i in range(k):
-                b.idx_dev = ip + 8 * i * batch_size
-                sc = C.cast(rows + 48 * i, C.POINTER(hb.StepScalars))
-                hb.check(lib.iqlhip_forward_backward(self._ctx, bref, sc, fptr, stream))
-                if world > 1:
-                    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self._dp_group)
-                hb.check(lib.iqlhip_apply_update(self._ctx, fptr, sc, stream))
-            self.total_it += k
-            done += k
+        """Data-parallel multi-step run without host syncs (= train_steps(..., return_losses=False))."""
+        self.train_steps(replay_buffer, n_steps, batch_size, seed=seed, return_losses=False)
 
     def train_on_buffer(self, replay_buffer, batch_size: int, seed: int = 0, sync: bool = False):
         """One step on rows drawn ON THE DEVICE from `replay_buffer` (no host index draw, no
@@ -532,7 +586,7 @@ class ImplicitQLearning:
         if idx is None or idx.numel() != batch_size:
             idx = torch.empty(batch_size, dtype=torch.int64, device=self._dev)
             self._idx_buf = idx
-        rank = torch.distributed.get_rank(self._dp_group) if self._dp_world > 1 else 0
+        rank = self._dp_rank if self._dp_world > 1 else 0
         hb.check(lib.iqlhip_draw_indices(idx.data_ptr(), batch_size, size, dp.rank_seed(seed, rank),
                                          int(self.total_it) * ((batch_size + 1) // 2), self._stream()))
         S, A = self._S, self._A
@@ -543,17 +597,66 @@ class ImplicitQLearning:
         return self._run_step(b, batch_size, sync)
 
     # ------------------------------------------------------------------ data parallel
-    def enable_data_parallel(self, process_group=None) -> None:
-        """One process per GPU: parameters replicated, each rank trains on its
-        own rows, the flat gradient (+3 loss words) is all-reduced (RCCL, sum) between the
-        backward and the fused Adam/Polyak launch.  Call after torch.distributed is up."""
+    def enable_data_parallel(self, process_group=None, exchange: str = "rccl", timeout_ms: int = 5000) -> None:
+        """One process per GPU: parameters replicated (rank 0's are broadcast once), each rank trains
+        on its own rows, the flat gradient (+3 loss words) is summed over the ranks between the backward and the
+        fused Adam/Polyak launch.  `exchange`:
+          "rccl"  ncclAllReduce issued by the library in-stream (and inside the captured chunk graphs);
+          "p2p"   the ranks' gradient buffers are mapped into each other (hipIpc) and the update kernel reads them
+                  directly over xGMI after a flag handshake — no collective call per step (one node, <= 8 ranks);
+          "both"  attach both (select with select_exchange(); "p2p" is selected);
+          "torch" torch.distributed.all_reduce between two library calls per step (any backend; eager train() only).
+        Call after torch.distributed is up; batch sizes must not grow afterwards (reserve_batch first)."""
         import torch.distributed as dist
         self._require_gpu()
+        if exchange not in ("rccl", "p2p", "both", "torch"):
+            raise ValueError("exchange must be 'rccl', 'p2p', 'both' or 'torch'")
         self._dp_group = process_group
         self._dp_world = dist.get_world_size(process_group)
-        if self._dp_world > 1:
+        self._dp_rank = dist.get_rank(process_group)
+        world, rank = self._dp_world, self._dp_rank
+        if world > 1 and not (exchange == "p2p" and dist.get_backend(process_group) == "gloo"):
             dp.broadcast_state((self._params_arena, self._target_arena, self._m_arena, self._v_arena), process_group,
                                src=dist.get_global_rank(process_group, 0) if process_group else 0)
+        elif world > 1:
+            dp.broadcast_state_host((self._params_arena, self._target_arena, self._m_arena, self._v_arena), process_group)
+        lib = hb.lib()
+        if exchange == "torch":
+            self._dp_exchange = "torch"
+            return
+        if exchange in ("rccl", "both"):
+            uid = (C.c_char * hb.IQLHIP_UNIQUE_ID_BYTES)()
+            if rank == 0:
+                hb.check(lib.iqlhip_comm_unique_id(uid))
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                                       group=process_group)
+            ubuf = C.create_string_buffer(box[0], hb.IQLHIP_UNIQUE_ID_BYTES)
+            hb.check(lib.iqlhip_allreduce_init(self._ctx, ubuf, rank, world))
+            self._dp_exchange = "rccl"
+        if exchange in ("p2p", "both"):
+            if world > hb.IQLHIP_MAX_WORLD:
+                raise ValueError(f"the p2p exchange serves one node (<= {hb.IQLHIP_MAX_WORLD} ranks), got {world}")
+            h = (C.c_char * hb.IQLHIP_IPC_HANDLE_BYTES)()
+            hb.check(lib.iqlhip_p2p_export(self._ctx, h, rank, world))
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(h.raw), group=process_group)
+            blob = C.create_string_buffer(b"".join(handles), world * hb.IQLHIP_IPC_HANDLE_BYTES)
+            hb.check(lib.iqlhip_p2p_attach(self._ctx, blob, int(timeout_ms)))
+            dist.barrier(group=process_group)       # every rank has mapped every block before anyone signals
+            self._dp_exchange = "p2p"
+
+    def select_exchange(self, exchange: str) -> None:
+        """Switch between attached in-library exchanges ("rccl" / "p2p"); collective: every rank must do the same."""
+        mode = {"rccl": hb.XCH_RCCL, "p2p": hb.XCH_P2P}[exchange]
+        hb.check(hb.lib().iqlhip_xch_select(self._ctx, mode))
+        self._dp_exchange = exchange
+
+    def exchange_status(self) -> Dict[str, int]:
+        """{"mode", "timed_out_step" (0 = no P2P wait ever timed out), "steps"}; synchronises the stream."""
+        st = (C.c_int64 * 3)()
+        hb.check(hb.lib().iqlhip_xch_status(self._ctx, st, self._stream()))
+        return {"mode": int(st[0]), "timed_out_step": int(st[1]), "steps": int(st[2])}
 
     def _dp_flat(self) -> torch.Tensor:
         n = int(hb.lib().iqlhip_grad_words(self._ctx))

@@ -1,0 +1,163 @@
+"""GPU tests of the multi-step driver's chunking and of the in-library gradient exchanges (RCCL all-reduce and the
+direct peer-read exchange), all through the C ABI.  Multi-rank cases start fresh child processes (before this
+process's children touch the GPU themselves) that share the one GPU of the test box."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import ROOT, load_golden, sub
+
+pytestmark = pytest.mark.gpu
+
+HYPER = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+LRS = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+
+
+def _mk(seed, S=17, A=6, N=5000, max_steps=1000):
+    import iql
+    from hip_helpers import build_hip_trainer
+    params = synth.synth_params(S, A, seed=seed)
+    data = synth.synth_transitions(N, S, A, seed=seed + 1)
+    buf = iql.ReplayBuffer(S, A, N, "cuda")
+    buf.load_d4rl_dataset({k: v.copy() for k, v in data.items()})
+    return params, buf, (lambda: build_hip_trainer(params, S, A, True, HYPER, LRS, max_steps))
+
+
+def _same_params(a, b):
+    from hip_helpers import read_params
+    pa, pb = read_params(a), read_params(b)
+    for n in pa:
+        for k in pa[n]:
+            assert np.array_equal(pa[n][k], pb[n][k]), (n, k)
+
+
+@pytest.mark.parametrize("K,B", [(64, 256), (70, 256), (129, 33), (200, 100)])
+def test_train_steps_chunks_equal_eager_steps(K, B):
+    """A run that spans graph chunks (64 steps each) and directly launched remainder steps equals K eager steps on
+    the same device index stream, bitwise: losses of every step, parameters, LR schedule."""
+    import iqlhip_binding as hb
+    params, buf, new = _mk(101)
+    g = new()
+    losses = g.train_steps(buf, K, B, seed=77)
+    assert losses.shape == (K, 3) and np.all(np.isfinite(losses)) and g.total_it == K
+    e = new()
+    idx = torch.empty(K * B, dtype=torch.int64, device="cuda")
+    hb.check(hb.lib().iqlhip_draw_indices(idx.data_ptr(), K * B, buf._size, 77, 0, torch.cuda.current_stream().cuda_stream))
+    for k in range(K):
+        log = e.train(buf.gather(idx[k * B:(k + 1) * B]))
+        assert [log["value_loss"], log["q_loss"], log["actor_loss"]] == [float(x) for x in losses[k]], k
+    _same_params(g, e)
+    assert g.actor_optimizer.param_groups[0]["lr"] == e.actor_optimizer.param_groups[0]["lr"]
+
+
+def test_train_steps_split_calls_equal_one_call():
+    """The result does not depend on how a run is cut into calls (20 + 5 + 64 + 41 == 130): the index stream position,
+    the scalar tables (incl. the look-ahead cache) and the loss ring line up across calls."""
+    params, buf, new = _mk(111)
+    a, b = new(), new()
+    la = a.train_steps(buf, 130, 256, seed=3)
+    parts = [b.train_steps(buf, n, 256, seed=3) for n in (20, 5, 64, 41)]
+    assert np.array_equal(la, np.concatenate(parts))
+    _same_params(a, b)
+
+
+def test_prepare_then_short_runs_never_capture():
+    """prepare_train_steps builds the chunk graph up front; runs shorter than a chunk launch directly."""
+    params, buf, new = _mk(121)
+    t = new()
+    t.prepare_train_steps(buf, 256)
+    l1 = t.train_steps(buf, 20, 256, seed=1)
+    u = new()
+    l2 = u.train_steps(buf, 20, 256, seed=1)
+    assert np.array_equal(l1, l2)
+
+
+@pytest.fixture
+def gloo_world1():
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 1000)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
+def test_exchange_world1_equals_plain_steps(gloo_world1, exchange):
+    """With a 1-rank group the exchange path (flatten -> ncclAllReduce captured in the chunk graph / flag handshake +
+    peer-read update) lands on the same parameters and losses as the plain three-launch step, bitwise, for eager
+    train() and for train_steps across a chunk boundary."""
+    params, buf, new = _mk(131)
+    plain, dpt = new(), new()
+    dpt.enable_data_parallel(exchange=exchange)
+    batch = buf.gather(torch.arange(256, device="cuda"))
+    assert plain.train(batch) == dpt.train(batch)
+    la = plain.train_steps(buf, 70, 256, seed=5)
+    lb = dpt.train_steps(buf, 70, 256, seed=5)
+    assert np.array_equal(la, lb)
+    _same_params(plain, dpt)
+    st = dpt.exchange_status()
+    assert st["timed_out_step"] == 0 and st["steps"] == 71
+    hb_mode = {"rccl": 1, "p2p": 2}[exchange]
+    assert st["mode"] == hb_mode
+
+
+def _run_ranks(scenario, world, tmp_path, timeout=300):
+    port = str(29700 + os.getpid() % 1000)
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    worker = os.path.join(ROOT, "tests", "dp_rank_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, scenario, str(r), str(world), port, str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)       # the host-side bound: a stuck exchange fails the test
+            outs.append(o.decode("utf-8", "replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} exited {p.returncode}:\n{outs[r][-3000:]}"
+    return [json.load(open(os.path.join(tmp_path, f"rank{r}.json"))) for r in range(world)]
+
+
+def test_p2p_two_ranks_reproduce_big_batch_fixture(tmp_path):
+    """Two processes on the one GPU, exchange blocks mapped through hipIpc: one DP step on the two halves of the
+    reference's B=2048 batch equals the reference's single-process step (fixture g8); after 70 more steps through
+    train_steps (graph chunk + direct steps, flag handshake inside) the replicas are still bit-identical."""
+    res = _run_ranks("fixture", 2, tmp_path)
+    z, meta = load_golden("g8_dp_B2048")
+    for r in res:
+        np.testing.assert_allclose(r["losses"], z["losses"], rtol=1e-5)
+        assert r["status"]["timed_out_step"] == 0 and r["status"]["steps"] == 71 and r["free_losses_finite"]
+    assert res[0]["losses"] == res[1]["losses"] and res[0]["free_losses_last"] == res[1]["free_losses_last"]
+    for tag in ("step1", "step71"):
+        a = np.load(os.path.join(tmp_path, f"{tag}_rank0.npz"))
+        b = np.load(os.path.join(tmp_path, f"{tag}_rank1.npz"))
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (tag, k)
+    a = np.load(os.path.join(tmp_path, "step1_rank0.npz"))
+    for net in ("vf", "q1", "q2", "pi", "qt1", "qt2"):
+        for t in ("w0", "w1", "b1", "w2"):
+            key = f"param.{net}.{t}"
+            if key not in z:
+                continue
+            want = z[key]
+            got = sub(a[f"{net}.{t}"], meta["stride"]).reshape(want.shape)
+            tol = 1e-6 if net.startswith("qt") else 2e-6
+            assert np.max(np.abs(got.astype(np.float64) - want)) <= tol, key
+
+
+def test_p2p_absent_peer_times_out_instead_of_hanging(tmp_path):
+    """A peer that never signals: the in-stream wait gives up after its timeout (300 ms here), the stream drains, the
+    status word names the step — nothing hangs and the process exits cleanly."""
+    res = _run_ranks("absent", 2, tmp_path, timeout=120)
+    assert res[0]["status"]["timed_out_step"] == 1 and res[0]["status"]["steps"] == 3
