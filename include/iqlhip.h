@@ -169,8 +169,8 @@ int iqlhip_train_steps(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int64
 /* Capture, instantiate and upload the hipGraph chunk iqlhip_train_steps replays for this (buffer, batch_rows,
  * inv_batch) — and, with an exchange attached, this exchange mode — WITHOUT running a step, so that no later
  * iqlhip_train_steps call pays for it (bench.py calls it before its timed region).  iqlhip_train_steps composes a run
- * of n steps from floor(n / IQLHIP_GRAPH_STEPS) replays of that one chunk graph and n % IQLHIP_GRAPH_STEPS steps
- * launched directly, so its cost per step does not depend on n and nothing is ever captured per value of n. */
+ * of n steps from replays of two fixed chunk graphs (IQLHIP_GRAPH_STEPS = 64 steps, then 16 steps) and fewer than 16
+ * steps launched directly, so its cost per step does not depend on n and nothing is ever captured per value of n. */
 int iqlhip_train_steps_prepare(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int32_t batch_rows, float inv_batch);
 
 /* ---- data-parallel gradient exchange (the reference has no multi-device code) ----------------

@@ -13,6 +13,7 @@
 #include <vector>
 
 #define GRAPH_STEPS IQLHIP_GRAPH_STEPS
+#define GRAPH_STEPS_SMALL 16     // second captured chunk size: the tail of a call runs 16 steps at a time in-graph too
 
 static thread_local std::string g_err;
 
@@ -45,19 +46,21 @@ struct DevGuard {
   ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
-// What a captured chunk graph (GRAPH_STEPS steps) depends on through frozen kernel arguments.  The number of steps
-// of a call is NOT part of it: a call is composed of replays of the one chunk graph plus directly launched steps.
+// What a captured chunk graph depends on through frozen kernel arguments.  The number of steps of a call is NOT part
+// of it: a call is composed of replays of the 64-step chunk graph, then of the 16-step one, plus < 16 directly
+// launched steps (kernel boundaries inside a graph are ~0.5 us shorter than between directly launched kernels).
 struct GraphKey {
   const float* rows = nullptr;
   int64_t ld = 0;
   int32_t B = 0;
+  int32_t K = 0;      // steps in the chunk: GRAPH_STEPS or GRAPH_STEPS_SMALL, never the caller's step count
   float* params = nullptr;
   float drop_p = 0.f;
   float inv_batch = 0.f;
   int xch = 0;        // exchange mode the chunk was captured with
   int parity = 0;     // P2P exchange: which flat buffer step 0 of the chunk writes
   bool operator==(const GraphKey& o) const {
-    return rows == o.rows && ld == o.ld && B == o.B && params == o.params && drop_p == o.drop_p &&
+    return rows == o.rows && ld == o.ld && B == o.B && K == o.K && params == o.params && drop_p == o.drop_p &&
            inv_batch == o.inv_batch && xch == o.xch && parity == o.parity;
   }
 };
@@ -902,18 +905,25 @@ extern "C" int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, ui
 // n % GRAPH_STEPS steps launched directly; both run the same launch sequence (enqueue_chunk) and read their
 // per-launch values (buffer size, RNG position, scalar table slice, ring position, exchange step) from device words
 // that iql_chunk_setup_kernel rewrites in front of every chunk.
-static int enqueue_chunk(iqlhip_ctx* c, hipStream_t st, const float* rows_dev, int64_t size_unused, int B, int K,
-                         float inv_batch, int mode, int parity) {
-  (void)size_unused;
+static int enqueue_chunk(iqlhip_ctx* c, hipStream_t st, const float* rows_dev, int B, int K, float inv_batch, int mode,
+                         int parity, const ChunkHdr* h, const iqlhip_step_scalars* sched_src) {
+  // one launch: the chunk's K * B row indices + the rows of step 0 (step k+1's rows are staged by the idle blocks of
+  // forward k into the other of the two staging buffers; forward k and backward k read buffer k & 1).  A directly
+  // launched chunk (h != null) hands its per-launch values to that kernel as arguments; a captured one reads them
+  // from the device words iql_chunk_setup_kernel writes in front of every replay.
   {
     const long long n = (long long)K * B;
     const int nb = (int)std::min<long long>((n / 2 + 255) / 256 + 1, 1024);
-    hipLaunchKernelGGL(iql_draw_indices_kernel, dim3(nb), dim3(256), 0, st, c->idx_chunk, n, 0ll, 0ull, 0ull,
-                       (const unsigned long long*)c->hdr);
+    if (h)
+      hipLaunchKernelGGL(iql_chunk_prologue_kernel<true>, dim3(nb), dim3(256), 0, st, c->hdr, *h, c->sched_cur, sched_src,
+                         K, c->idx_chunk, n, rows_dev, (long long)c->row_ld, c->xb, B);
+    else {
+      ChunkHdr none;
+      memset(&none, 0, sizeof none);
+      hipLaunchKernelGGL(iql_chunk_prologue_kernel<false>, dim3(nb), dim3(256), 0, st, c->hdr, none, c->sched_cur,
+                         (const iqlhip_step_scalars*)nullptr, 0, c->idx_chunk, n, rows_dev, (long long)c->row_ld, c->xb, B);
+    }
   }
-  // rows of step 0 (standalone gather); step k+1's are staged by the idle blocks of forward k into the other of
-  // the two staging buffers (forward k and backward k read buffer k & 1)
-  launch_gather(c, rows_dev, c->idx_chunk, B, st);
   if (c->drop_p > 0.f) launch_dropmask(c, 0, 0, c->hdr, 0, st);   // keep-bits of step 0 (seed / first step from hdr)
   iqlhip_step_scalars sc0;
   memset(&sc0, 0, sizeof sc0);
@@ -941,7 +951,7 @@ static int enqueue_chunk(iqlhip_ctx* c, hipStream_t st, const float* rows_dev, i
 static int chunk_graph(iqlhip_ctx* c, const GraphKey& key, hipGraphExec_t* out, iqlhip_ctx::CachedGraph** slot) {
   for (auto& g : c->graphs)
     if (g.key == key) { g.stamp = ++c->graph_clock; *out = g.exec; if (slot) *slot = &g; return IQLHIP_OK; }
-  if (c->graphs.size() >= 6) {   // evict the least recently used — after its last replay has finished
+  if (c->graphs.size() >= 8) {   // evict the least recently used — after its last replay has finished
     size_t lru = 0;
     for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].stamp < c->graphs[lru].stamp) lru = i;
     if (c->graphs[lru].last) HIPCHK(hipStreamSynchronize(c->graphs[lru].last));
@@ -952,7 +962,7 @@ static int chunk_graph(iqlhip_ctx* c, const GraphKey& key, hipGraphExec_t* out, 
   hipStream_t cs = c->cap_stream;
   // (relaxed: a collective library may make calls during capture that the stricter modes forbid)
   HIPCHK(hipStreamBeginCapture(cs, key.xch == IQLHIP_XCH_RCCL ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
-  int rc = enqueue_chunk(c, cs, key.rows, 0, key.B, GRAPH_STEPS, key.inv_batch, key.xch, key.parity);
+  int rc = enqueue_chunk(c, cs, key.rows, key.B, key.K, key.inv_batch, key.xch, key.parity, nullptr, nullptr);
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(cs, &graph);
   if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -974,9 +984,10 @@ static int check_train_args(const iqlhip_ctx* c, const float* rows_dev, int64_t 
   return IQLHIP_OK;
 }
 
-static GraphKey make_key(const iqlhip_ctx* c, const float* rows_dev, int64_t ld, int32_t B, float inv_batch, int parity) {
+static GraphKey make_key(const iqlhip_ctx* c, const float* rows_dev, int64_t ld, int32_t B, int32_t K, float inv_batch,
+                         int parity) {
   GraphKey key;
-  key.rows = rows_dev; key.ld = ld; key.B = B; key.params = c->params; key.drop_p = c->drop_p;
+  key.rows = rows_dev; key.ld = ld; key.B = B; key.K = K; key.params = c->params; key.drop_p = c->drop_p;
   key.inv_batch = inv_batch; key.xch = c->xch_mode;
   key.parity = (c->xch_mode == IQLHIP_XCH_P2P) ? parity : 0;
   return key;
@@ -986,13 +997,77 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
   int rc = check_train_args(c, rows_dev, ld, B);
   if (rc) return rc;
   DevGuard guard(c->device);
-  for (int parity = 0; parity < ((c->xch_mode == IQLHIP_XCH_P2P) ? 2 : 1); ++parity) {
-    hipGraphExec_t gexec = nullptr;
-    rc = chunk_graph(c, make_key(c, rows_dev, ld, B, inv_batch, parity), &gexec, nullptr);
-    if (rc) return rc;
-    HIPCHK(hipGraphUpload(gexec, c->cap_stream));
-  }
-  HIPCHK(hipStreamSynchronize(c->cap_stream));
+  HIPCHK(hipDeviceSynchronize());       // a one-off set-up call: ordered after everything queued on any stream
+  hipStream_t cs = c->cap_stream;
+  // Each chunk graph is captured, instantiated, uploaded AND replayed once, so that its first replay inside a caller's
+  // timed region costs what every later one does (a first replay is ~50-100 us slower, and the first launch of a
+  // kernel loads its code).  The rehearsal must not train: the parameter, moment and target arenas are saved before
+  // and restored after it; it reads row 0 only (size = 1); scratch, loss words and ring are transient anyway.  Under
+  // data parallelism the rehearsal runs the exchange too — every rank must call prepare (the same number of times).
+  const size_t np_b = (size_t)c->L.n_params * sizeof(float), nt_b = (size_t)c->L.n_target * sizeof(float);
+  char* save = nullptr;
+  HIPCHK(hipMalloc((void**)&save, 3 * np_b + nt_b));
+  auto copy_all = [&](bool restore) -> hipError_t {
+    float* arenas[4] = {c->params, c->m, c->v, c->target};
+    size_t off = 0;
+    for (int i = 0; i < 4; ++i) {
+      const size_t nb = (i == 3) ? nt_b : np_b;
+      hipError_t e = restore ? hipMemcpyAsync(arenas[i], save + off, nb, hipMemcpyDeviceToDevice, cs)
+                             : hipMemcpyAsync(save + off, arenas[i], nb, hipMemcpyDeviceToDevice, cs);
+      if (e != hipSuccess) return e;
+      off += nb;
+    }
+    return hipSuccess;
+  };
+  hipError_t e = copy_all(false);
+  if (e != hipSuccess) { (void)hipFree(save); return fail(IQLHIP_EHIP, "prepare: save arenas: %s", hipGetErrorString(e)); }
+  const int slot = c->sched_slot;
+  c->sched_slot = (c->sched_slot + 1) & 3;
+  rc = IQLHIP_OK;
+  do {
+    if (hipEventSynchronize(c->sched_done[slot]) != hipSuccess) { rc = fail(IQLHIP_EHIP, "prepare: event"); break; }
+    iqlhip_step_scalars benign;
+    memset(&benign, 0, sizeof benign);
+    benign.bc2_sqrt[0] = benign.bc2_sqrt[1] = benign.bc2_sqrt[2] = 1.f;
+    benign.beta2 = 1.f; benign.eps = 1e-8f; benign.grad_scale = 1.f; benign.inv_batch = inv_batch;
+    for (int k = 0; k < GRAPH_STEPS; ++k) c->sched_pin[slot][k] = benign;
+    for (int K : {GRAPH_STEPS, GRAPH_STEPS_SMALL}) {
+      for (int rep = 0; rep < ((c->xch_mode == IQLHIP_XCH_P2P) ? 2 : 1) && !rc; ++rep) {
+        const int parity = (int)(c->xstep & 1ull);     // P2P: K is even, so the second graph is reached by one
+        hipGraphExec_t gexec = nullptr;               // extra directly launched step between the two rehearsals
+        iqlhip_ctx::CachedGraph* cg = nullptr;
+        rc = chunk_graph(c, make_key(c, rows_dev, ld, B, K, inv_batch, parity), &gexec, &cg);
+        if (rc) break;
+        if (hipGraphUpload(gexec, cs) != hipSuccess) { rc = fail(IQLHIP_EHIP, "hipGraphUpload failed"); break; }
+        ChunkHdr h;
+        memset(&h, 0, sizeof h);
+        h.w[HDR_SIZE] = 1ull;
+        h.w[HDR_DROP_STEP] = c->drop_step;
+        h.w[HDR_DROP_SEED] = c->drop_seed;
+        h.w[HDR_XSTEP] = c->xstep;
+        hipLaunchKernelGGL(iql_chunk_setup_kernel, dim3(1), dim3(256), 0, cs, c->hdr, h, c->sched_cur,
+                           (const iqlhip_step_scalars*)c->sched_pin[slot], K);
+        if (hipGraphLaunch(gexec, cs) != hipSuccess) { rc = fail(IQLHIP_EHIP, "prepare: hipGraphLaunch failed"); break; }
+        cg->last = cs;
+        if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += (unsigned long long)K;
+        if (c->xch_mode == IQLHIP_XCH_P2P && rep == 0) {
+          // one directly launched step flips the buffer parity for the other captured variant
+          ChunkHdr h1 = h;
+          h1.w[HDR_XSTEP] = c->xstep;
+          rc = enqueue_chunk(c, cs, rows_dev, B, 1, inv_batch, c->xch_mode, (int)(c->xstep & 1ull), &h1, c->sched_pin[slot]);
+          if (rc) break;
+          c->xstep += 1ull;
+        }
+      }
+      if (rc) break;
+    }
+  } while (0);
+  (void)hipEventRecord(c->sched_done[slot], cs);
+  e = copy_all(true);
+  hipError_t e2 = hipStreamSynchronize(cs);
+  (void)hipFree(save);
+  if (rc) return rc;
+  if (e != hipSuccess || e2 != hipSuccess) return fail(IQLHIP_EHIP, "prepare: restore arenas: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   return IQLHIP_OK;
 }
 
@@ -1013,7 +1088,6 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
   HIPCHK(hipEventSynchronize(c->sched_done[slot]));
   memcpy(c->sched_pin[slot], sc, (size_t)K * sizeof(iqlhip_step_scalars));
   const float inv_batch = sc[0].inv_batch;
-  const unsigned long long per_step = (unsigned long long)((B + 1) / 2);      // Philox counters one step's draw uses
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (c->timing) {
     rc = ensure_events(c, c->ev_used + 2);
@@ -1023,28 +1097,31 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
   }
   int done = 0;
   while (done < K) {
-    const int n = std::min(GRAPH_STEPS, K - done);
+    const int left = K - done;
+    const int n = left >= GRAPH_STEPS ? GRAPH_STEPS : (left >= GRAPH_STEPS_SMALL ? GRAPH_STEPS_SMALL : left);
     ChunkHdr h;
     memset(&h, 0, sizeof h);
     h.w[HDR_SIZE] = (unsigned long long)size;
     h.w[HDR_SEED] = (unsigned long long)seed;
-    h.w[HDR_OFFSET] = (unsigned long long)stream_offset + (unsigned long long)done * per_step;
+    // one Philox counter yields two indices; `done` is a multiple of GRAPH_STEPS_SMALL (even), so a chunk starts on a
+    // counter boundary and the call's index stream is the one a single draw of K * B indices would give
+    h.w[HDR_OFFSET] = (unsigned long long)stream_offset + ((unsigned long long)done * (unsigned long long)B) / 2ull;
     h.w[HDR_DROP_STEP] = c->drop_step;
     h.w[HDR_DROP_SEED] = c->drop_seed;
     h.w[HDR_BASE] = (unsigned long long)done;
     h.w[HDR_XSTEP] = c->xstep;
-    hipLaunchKernelGGL(iql_chunk_setup_kernel, dim3(1), dim3(256), 0, st, c->hdr, h, c->sched_cur,
-                       (const iqlhip_step_scalars*)(c->sched_pin[slot] + done), n);
+    const iqlhip_step_scalars* src = c->sched_pin[slot] + done;
     const int parity = (int)(c->xstep & 1ull);
-    if (n == GRAPH_STEPS) {
+    if (n == GRAPH_STEPS || n == GRAPH_STEPS_SMALL) {
       hipGraphExec_t gexec = nullptr;
       iqlhip_ctx::CachedGraph* cg = nullptr;
-      rc = chunk_graph(c, make_key(c, rows_dev, ld, B, inv_batch, parity), &gexec, &cg);
+      rc = chunk_graph(c, make_key(c, rows_dev, ld, B, n, inv_batch, parity), &gexec, &cg);
       if (rc) return rc;
+      hipLaunchKernelGGL(iql_chunk_setup_kernel, dim3(1), dim3(256), 0, st, c->hdr, h, c->sched_cur, src, n);
       HIPCHK(hipGraphLaunch(gexec, st));
       cg->last = st;
     } else {
-      rc = enqueue_chunk(c, st, rows_dev, size, B, n, inv_batch, c->xch_mode, parity);
+      rc = enqueue_chunk(c, st, rows_dev, B, n, inv_batch, c->xch_mode, parity, &h, src);
       if (rc) return rc;
     }
     c->drop_step += (unsigned long long)n;

@@ -1587,10 +1587,28 @@ __global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long
 // 16-byte accesses at SYSTEM scope (sc0 sc1): the load misses every cache level that is not coherent with another
 // device's writes (IPC-mapped peer memory over xGMI), the store is written through to memory.  There is no 16-byte
 // atomic, so these are the instructions the memory model uses for system-scope relaxed accesses, issued by hand.
+// (load and wait are ONE asm statement: the compiler does not know that the load completes asynchronously and would
+//  otherwise be free to copy the destination registers before a separate s_waitcnt has run)
 __device__ __forceinline__ f32x4 load16_sys(const float* p) {
   f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
   return v;
+}
+// eight such loads in flight together (one fabric round trip), then one wait
+__device__ __forceinline__ void load16_sys_x8(f32x4 (&v)[8], const float* const (&p)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc0 sc1\n\t"
+      "global_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc0 sc1\n\t"
+      "global_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+      : "memory");
 }
 __device__ __forceinline__ void store16_sys(float* p, f32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
@@ -1688,10 +1706,12 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     f32x4 gr;
     if (PEER) {
       // all ranks' contributions requested together (one fabric round trip), summed in rank order
-      f32x4 pv[IQLHIP_MAX_WORLD];
+      static_assert(IQLHIP_MAX_WORLD == 8, "load16_sys_x8");
+      f32x4 pv[8];
+      const float* pp[8];
 #pragma unroll
-      for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) pv[r] = load16_sys(u.peer_flat[min(r, u.n_peer - 1)] + e);
-      wait_vm0();
+      for (int r = 0; r < 8; ++r) pp[r] = u.peer_flat[min(r, u.n_peer - 1)] + e;
+      load16_sys_x8(pv, pp);
       gr = pv[0];
 #pragma unroll
       for (int r = 1; r < IQLHIP_MAX_WORLD; ++r) if (r < u.n_peer) gr += pv[r];
@@ -1728,12 +1748,7 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     float l[3];
     if (PEER) {
       f32x4 t = load16_sys(u.peer_flat[0] + u.L.n_params);
-      wait_vm0();
-      for (int r = 1; r < u.n_peer; ++r) {
-        const f32x4 tr = load16_sys(u.peer_flat[r] + u.L.n_params);
-        wait_vm0();
-        t += tr;
-      }
+      for (int r = 1; r < u.n_peer; ++r) t += load16_sys(u.peer_flat[r] + u.L.n_params);
       l[0] = t[0]; l[1] = t[1]; l[2] = t[2];
     } else if (u.flat_grads) {
       l[0] = u.flat_grads[u.L.n_params + 0];
@@ -1851,6 +1866,57 @@ __global__ void iql_rows_gather_kernel(const float* rows, long long ld, int S, i
     else if (c < 2 * S + A) ns[i * S + (c - S - A)] = v;
     else if (c == 2 * S + A) r[i] = v;
     else d[i] = v;
+  }
+}
+
+// First launch of a chunk of steps: draws the chunk's n_idx row indices (same stream as iql_draw_indices_kernel) AND
+// gathers the rows of the chunk's step 0 into xb (the indices a block has just drawn travel through LDS), so that a
+// chunk starts with one launch instead of three.  SETUP (directly launched chunks): the per-launch values arrive as the
+// kernel argument `h`, and block 0 also publishes them (hdr words + the chunk's slice of the scalar table) for the
+// kernels that follow; !SETUP (captured chunks, frozen arguments): they are read from hdr, which
+// iql_chunk_setup_kernel has written in front of the replay.
+template <bool SETUP>
+__global__ __launch_bounds__(256) void iql_chunk_prologue_kernel(unsigned long long* hdr, ChunkHdr h,
+                                                                 iqlhip_step_scalars* sched_cur,
+                                                                 const iqlhip_step_scalars* sched_src, int n_sched,
+                                                                 long long* idx, long long n_idx, const float* rows,
+                                                                 long long ld, float* xb, int B) {
+  __shared__ long long s_idx[512];
+  unsigned long long size, seed, offset;
+  if (SETUP) {
+    size = h.w[HDR_SIZE]; seed = h.w[HDR_SEED]; offset = h.w[HDR_OFFSET];
+    if (blockIdx.x == 0) {
+      if (threadIdx.x < HDR_WORDS) hdr[threadIdx.x] = h.w[threadIdx.x];
+      const float* s = (const float*)sched_src;
+      float* d = (float*)sched_cur;
+      const int words = n_sched * (int)(sizeof(iqlhip_step_scalars) / sizeof(float));
+      for (int i = threadIdx.x; i < words; i += 256) d[i] = s[i];
+    }
+  } else {
+    size = hdr[HDR_SIZE]; seed = hdr[HDR_SEED]; offset = hdr[HDR_OFFSET];
+  }
+  const long long n_pairs = (n_idx + 1) / 2;
+  bool first = true;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_pairs; i += (long long)gridDim.x * 256) {
+    const unsigned long long ctr = offset + (unsigned long long)i;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x49514C48u /* "IQLH" */, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const unsigned long long r0 = ((unsigned long long)c[1] << 32) | c[0];
+    const unsigned long long r1 = ((unsigned long long)c[3] << 32) | c[2];
+    const long long i0 = (long long)__umul64hi(r0, size), i1 = (long long)__umul64hi(r1, size);
+    idx[2 * i] = i0;
+    if (2 * i + 1 < n_idx) idx[2 * i + 1] = i1;
+    if (first) { s_idx[2 * threadIdx.x] = i0; s_idx[2 * threadIdx.x + 1] = i1; first = false; }
+  }
+  // rows [512 b, 512 b + 512) of step 0 belong to the pairs this block drew in its first pass
+  const int r_lo = (int)blockIdx.x * 512;
+  if (r_lo >= B) return;                 // (block-uniform)
+  __syncthreads();
+  const int q = (int)(ld >> 2);
+  const int n_r = min(512, B - r_lo);
+  for (int e = threadIdx.x; e < n_r * q; e += 256) {
+    const int r = e / q, c4 = e - r * q;
+    *(f32x4*)(xb + (long long)(r_lo + r) * ld + 4 * c4) = *(const f32x4*)(rows + s_idx[r] * ld + 4 * c4);
   }
 }
 

@@ -486,8 +486,8 @@ class ImplicitQLearning:
         tab[:, 11] = inv_batch
         return tab
 
-    def _table_key(self, k: int, inv_batch: float):
-        return (k, float(inv_batch), tuple(sorted(self._adam_t.items())), self._schedule_state(),
+    def _table_key(self, inv_batch: float):
+        return (float(inv_batch), tuple(sorted(self._adam_t.items())), self._schedule_state(),
                 tuple(sorted(self._current_lrs().items())), self._adam_hyper())
 
     def _scalar_table(self, k: int, inv_batch: float) -> np.ndarray:
@@ -495,12 +495,14 @@ class ImplicitQLearning:
         float32 once per step like torch does); advances the Adam step counts and the scheduler.  A table computed
         ahead of time by _lookahead_table (while the GPU was busy with the previous chunk) is used when the state it
         was computed for is still the current one."""
-        key = self._table_key(k, inv_batch)
+        key = self._table_key(inv_batch)
         cached = self._table_cache
         self._table_cache = None
-        if cached is not None and cached[0] == key:
-            _, tab, sched_state = cached
-            self._commit_schedule(sched_state)
+        if cached is not None and cached[0] == key and cached[1].shape[0] >= k:
+            # rows depend on the absolute step only: the first k rows of a longer look-ahead are this call's table
+            _, tab_all, lr_after, (e0, c0) = cached
+            tab = np.ascontiguousarray(tab_all[:k])
+            self._commit_schedule((float(lr_after[k - 1]), None if e0 is None else e0 + k, None if c0 is None else c0 + k))
         else:
             lr_pi = self._advance_schedule(k)
             tab = self._build_table(k, inv_batch, self._adam_t, lr_pi)
@@ -509,13 +511,17 @@ class ImplicitQLearning:
         return tab
 
     def _lookahead_table(self, k: int, inv_batch: float) -> None:
-        """Precompute the table of the k steps AFTER the ones just launched (host work overlapped with the GPU)."""
-        pk = self._peek_schedule(k)
+        """Precompute the table of the steps AFTER the ones just launched (host work overlapped with the GPU): at least
+        64 rows, so that a following call of any length up to that finds its rows ready."""
+        k = max(int(k), 64)
+        pk = self._peek_schedule(k + 1)
         if pk is None:
             return
-        lr_pi, sched_state = pk
-        self._table_cache = (self._table_key(k, inv_batch), self._build_table(k, inv_batch, self._adam_t, lr_pi),
-                             sched_state)
+        lr_used, _ = pk                     # lr_used[i] = learning rate step i uses = the rate AFTER i steps
+        sch = self.actor_lr_schedule
+        state0 = (None, None) if sch is None else (sch.last_epoch, sch._step_count)
+        self._table_cache = (self._table_key(inv_batch), self._build_table(k, inv_batch, self._adam_t, lr_used[:k]),
+                             lr_used[1:], state0)
 
     def _train_steps_args(self, replay_buffer, batch_size: int):
         self._prepare(batch_size)

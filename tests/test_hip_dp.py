@@ -37,7 +37,7 @@ def _same_params(a, b):
             assert np.array_equal(pa[n][k], pb[n][k]), (n, k)
 
 
-@pytest.mark.parametrize("K,B", [(64, 256), (70, 256), (129, 33), (200, 100)])
+@pytest.mark.parametrize("K,B", [(64, 256), (70, 256), (100, 256), (129, 33), (200, 100)])
 def test_train_steps_chunks_equal_eager_steps(K, B):
     """A run that spans graph chunks (64 steps each) and directly launched remainder steps equals K eager steps on
     the same device index stream, bitwise: losses of every step, parameters, LR schedule."""
@@ -96,6 +96,9 @@ def test_exchange_world1_equals_plain_steps(gloo_world1, exchange):
     params, buf, new = _mk(131)
     plain, dpt = new(), new()
     dpt.enable_data_parallel(exchange=exchange)
+    dpt.prepare_train_steps(buf, 256)        # rehearses the captured chunks (exchange included) without training
+    rehearsed = dpt.exchange_status()["steps"]
+    assert rehearsed == {"rccl": 64 + 16, "p2p": 2 * (64 + 16) + 2}[exchange]
     batch = buf.gather(torch.arange(256, device="cuda"))
     assert plain.train(batch) == dpt.train(batch)
     la = plain.train_steps(buf, 70, 256, seed=5)
@@ -103,7 +106,7 @@ def test_exchange_world1_equals_plain_steps(gloo_world1, exchange):
     assert np.array_equal(la, lb)
     _same_params(plain, dpt)
     st = dpt.exchange_status()
-    assert st["timed_out_step"] == 0 and st["steps"] == 71
+    assert st["timed_out_step"] == 0 and st["steps"] == rehearsed + 71
     hb_mode = {"rccl": 1, "p2p": 2}[exchange]
     assert st["mode"] == hb_mode
 

@@ -199,6 +199,51 @@ def test_scalar_table_matches_torch_adam_scalars():
     assert tr._adam_t == {"v": 10, "q": 10, "pi": 10}
 
 
+def test_lookahead_scalar_table_equals_direct_computation():
+    """The table rows computed ahead of time (while the GPU runs the previous chunk) and sliced to the next call's
+    length are bit-equal to rows computed on demand, for any sequence of call lengths, across the cosine restart."""
+    a = _cpu_trainer(3, 2, True, max_steps=100)
+    b = _cpu_trainer(3, 2, True, max_steps=100)
+    for k in (5, 20, 64, 1, 70, 130, 3):
+        ta = a._scalar_table(k, 1.0 / 256)
+        a._lookahead_table(k, 1.0 / 256)
+        tb = b._scalar_table(k, 1.0 / 256)               # never looks ahead
+        assert b._table_cache is None and np.array_equal(ta, tb), k
+        assert a.actor_lr_schedule.state_dict() == b.actor_lr_schedule.state_dict()
+        assert a._adam_t == b._adam_t
+    # a changed learning rate invalidates the look-ahead
+    a._lookahead_table(10, 1.0 / 256)
+    for t in (a, b):
+        t.v_optimizer.param_groups[0]["lr"] = 1e-3
+    assert np.array_equal(a._scalar_table(10, 1.0 / 256), b._scalar_table(10, 1.0 / 256))
+
+
+def test_bench_launcher_fans_out_one_rank_per_gpu_without_touching_the_gpu():
+    """`python bench.py --gpus N` with no launcher in the environment starts N fresh rank processes itself (dry run:
+    the plan as data); a launcher world size that contradicts --gpus is refused; configs[3] rows at N > 1."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bench = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-run-launch"],
+                         env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    plan = json.loads(out.stdout)
+    assert plan["self_launch"] and plan["gpus"] == 8 and plan["rows"] == 10_000_000 and len(plan["ranks"]) == 8
+    ports = {r["env"]["MASTER_PORT"] for r in plan["ranks"]}
+    assert len(ports) == 1
+    for i, r in enumerate(plan["ranks"]):
+        assert r["rank"] == i and r["env"]["RANK"] == str(i) and r["env"]["LOCAL_RANK"] == str(i)
+        assert r["env"]["WORLD_SIZE"] == "8" and r["env"]["MASTER_ADDR"] == "127.0.0.1"
+        assert r["cmd"][1] == bench and "--dry-run-launch" not in r["cmd"] and r["cmd"][2:6] == ["--gpus", "8", "--steps", "20"]
+    one = json.loads(subprocess.run([sys.executable, bench, "--dry-run-launch"], env=env, capture_output=True, text=True,
+                                    timeout=60).stdout)
+    assert not one["self_launch"] and one["rows"] == 1_000_000 and one["ranks"] == []
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, bench, "--gpus", "8"], env=env2, capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "WORLD_SIZE=2" in bad.stderr
+
+
 def test_unsupported_configurations_fail_loudly():
     tr = _cpu_trainer()
     tr.v_optimizer.param_groups[0]["weight_decay"] = 0.1
