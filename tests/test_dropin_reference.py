@@ -136,3 +136,47 @@ def test_checkpoints_are_interchangeable_with_the_reference(ref_jsrl, tmp_path):
     r3.load_state_dict(torch.load(f1, weights_only=True))
     log_a, log_b = r3.train(batch), r2.train(batch)
     assert log_a == log_b
+
+
+def test_jsrl_host_logic_is_unchanged_by_the_drop_in(ref_jsrl):
+    """SURVEY §8c "G9 JSRL host logic" (fixture g13, generated with the reference's OWN iql): prepare_finetuning's
+    curricula, the horizon_update_callback trace over a fixed evaluation sequence and timestep_horizon's truth table
+    come out the same when jsrl_utils.py runs against this repo's `iql`."""
+    import contextlib
+    import io
+    import json
+    jsrl, _ = ref_jsrl
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_jsrl_hostlogic.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+
+    class C(Cfg):
+        n_curriculum_stages = meta["n_curriculum_stages"]
+        rolling_mean_n, tolerance = meta["rolling_mean_n"], meta["tolerance"]
+        batch_size = 256
+
+    cfg = jsrl.prepare_finetuning(meta["init_horizon"], C())
+    assert np.array_equal(np.asarray(cfg.all_curriculum_stages, dtype=np.float64), z["stages_time_step"])
+    assert np.array_equal(np.asarray(cfg.all_agent_types, dtype=np.float64), z["agent_types_disabled"])
+    c2 = C()
+    c2.no_agent_types, c2.horizon_fn = False, "goal_dist"
+    c2 = jsrl.prepare_finetuning(12.5, c2)
+    assert np.array_equal(np.asarray(c2.all_curriculum_stages, dtype=np.float64), z["stages_goal_dist"])
+    assert np.array_equal(np.asarray(c2.all_agent_types, dtype=np.float64), z["agent_types_enabled"])
+    trace = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for r in z["evals"]:
+            cfg = jsrl.horizon_update_callback(cfg, float(r))
+            trace.append([cfg.curriculum_stage_idx, cfg.curriculum_stage, cfg.agent_type_stage, cfg.best_eval_score,
+                          float(np.mean(cfg.rolling_mean_rews))])
+    assert np.array_equal(np.asarray(trace, dtype=np.float64), z["callback_trace"])
+    t = jsrl.prepare_finetuning(meta["init_horizon"], C())
+    for row in z["timestep_horizon_table"]:
+        stage_idx, ep_type, step, use, val = row
+        if stage_idx < 0:
+            t.curriculum_stage = np.nan
+        else:
+            t.curriculum_stage_idx = int(stage_idx)
+            t.curriculum_stage = t.all_curriculum_stages[int(stage_idx)]
+        t.ep_agent_type = ep_type
+        got_use, got_val = jsrl.timestep_horizon(int(step), None, None, t)
+        assert (float(got_use), float(got_val)) == (use, val), row

@@ -1,0 +1,215 @@
+"""GPU tests of the rows round 1 left CPU-only: checkpoints of an arena-backed trainer, the JSRL
+offline -> online hand-off (§8a H2), configs[3]'s 10 M-row buffer and configs[4]'s per-GPU share on the bf16 path
+against the reference fixture / the oracle.  Everything goes through the C ABI (libiqlhip.so)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import (assert_losses, check_state_against_golden, check_step_against_golden, load_golden,
+                     single_step_inputs, step_batch)
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from hip_helpers import build_hip_trainer, read_moments, read_params, to_torch_batch, unflatten_grads
+    return build_hip_trainer, read_moments, read_params, to_torch_batch, unflatten_grads
+
+
+def _losses(log):
+    return [log["value_loss"], log["q_loss"], log["actor_loss"]]
+
+
+@pytest.mark.parametrize("name", ["g11_resume_S17A6_gauss", "g11_resume_S29A8_det"])
+def test_checkpoint_of_gpu_trained_trainer_resumes_like_the_reference(name, tmp_path):
+    """state_dict() of a GPU-trained trainer holds the reference's post-training parameters, Adam moments, step
+    counts and schedule; written with torch.save and loaded (weights_only) into a FRESH arena-backed trainer, the next
+    step equals the reference's continuation — including the quirk q_target == qf after a load (iql.py:581-593)."""
+    build, read_moments, read_params, to_tb, _ = _hip()
+    z, meta = load_golden(name)
+    S, A, B, T = meta["S"], meta["A"], meta["B"], meta["max_steps"]
+    hyper = dict(meta["hyper"])
+    tr = build(synth.synth_params(S, A, seed=meta["seed"], gaussian=meta["gaussian"]), S, A, meta["gaussian"], hyper,
+               meta["lrs"], T)
+    for k in range(meta["n_before"]):
+        log = tr.train(to_tb(step_batch(S, A, B, meta["batch_seed0"] + k)))
+        assert_losses(_losses(log), z["losses_before"][k], 1e-5, f"step {k}")
+    sd = tr.state_dict()
+    check_state_against_golden(z, meta, "ckpt", read_params(tr), read_moments(tr), param_atol=4e-6, moment_rtol=3e-5)
+    assert float(sd["q_optimizer"]["state"][0]["step"]) == float(z["ckpt.q_step"][0]) == meta["n_before"]
+    assert sd["total_it"] == meta["n_before"]
+    assert abs(sd["actor_optimizer"]["param_groups"][0]["lr"] - float(z["ckpt.actor_lr"][0])) <= 1e-18
+    assert sd["actor_lr_schedule"]["last_epoch"] == meta["n_before"]
+    f = tmp_path / "ckpt.pt"
+    torch.save(sd, f)
+    fresh = build(synth.synth_params(S, A, seed=meta["seed"] + 1, gaussian=meta["gaussian"]), S, A, meta["gaussian"],
+                  hyper, meta["lrs"], T)
+    fresh.load_state_dict(torch.load(f, weights_only=True))
+    assert fresh.total_it == meta["n_before"] and fresh._adam_t == {"v": 3, "q": 3, "pi": 3}
+    pf = read_params(fresh)
+    for q, t in (("q1", "qt1"), ("q2", "qt2")):
+        for k in pf[q]:
+            assert np.array_equal(pf[q][k], pf[t][k])          # target re-created as a copy of qf
+    for n in ("vf", "q1", "q2", "pi"):
+        for k, v in read_params(tr)[n].items():
+            assert np.array_equal(v, pf[n][k]), (n, k)
+    ma, mb = read_moments(tr), read_moments(fresh)
+    for mv in ("m", "v"):
+        for n in ma[mv]:
+            for k in ma[mv][n]:
+                assert np.array_equal(ma[mv][n][k], mb[mv][n][k]), (mv, n, k)
+    log = fresh.train(to_tb(step_batch(S, A, B, meta["batch_seed0"] + meta["n_before"])))
+    assert_losses(_losses(log), z["losses_after"], 1e-5, "after load")
+    check_state_against_golden(z, meta, "after", read_params(fresh), read_moments(fresh), param_atol=4e-6,
+                               moment_rtol=3e-5, target_atol=1e-6)
+    assert abs(fresh.actor_optimizer.param_groups[0]["lr"] - float(z["after.actor_lr"][0])) <= 1e-18
+    assert fresh.total_it == meta["total_it_after"]
+    # the graph path continues from a loaded checkpoint as well (arenas, step counts and schedule are all live)
+    import iql
+    data = synth.synth_transitions(2000, S, A, seed=5)
+    buf = iql.ReplayBuffer(S, A, 2000, "cuda")
+    buf.load_d4rl_dataset(data)
+    losses = fresh.train_steps(buf, 20, 256, seed=1)
+    assert np.all(np.isfinite(losses)) and fresh.total_it == meta["total_it_after"] + 20
+
+
+def test_jsrl_handoff_on_arena_backed_trainers_matches_reference():
+    """The offline -> online switch of jsrl_w_iql.py on the GPU: guide (2 offline steps) -> learner built the way
+    jsrl_utils.make_actor builds it (:252-282: fresh nets and optimizers, max_steps=None) -> get_learning_agent's
+    partial_load_state_dict(guide.state_dict()) and total_it = offline_iterations (:350-355) -> a fresh 10 000-row
+    online ReplayBuffer holding ONE transition -> sample(256) (256 copies of that row, jsrl_w_iql.py:540-548) ->
+    train.  Losses, gradients' effect (post-step parameters, moments), target against the reference fixture g12."""
+    import iql
+    build, read_moments, read_params, to_tb, _ = _hip()
+    z, meta = load_golden("g12_jsrl_handoff_S29A8")
+    S, A, B = meta["S"], meta["A"], meta["B"]
+    hyper = dict(meta["hyper"])
+    guide = build(synth.synth_params(S, A, seed=meta["seed"]), S, A, True, hyper, meta["lrs"], meta["offline_iterations"])
+    for k in range(2):
+        b = step_batch(S, A, B, meta["guide_batch_seed0"] + k, p_done=0.001, antmaze_rewards=True)
+        assert_losses(_losses(guide.train(to_tb(b))), z["guide_losses"][k], 1e-5, f"guide step {k}")
+    # make_actor (jsrl_utils.py:252-282), with this repo's classes
+    torch.manual_seed(1234)
+    dev = "cuda"
+    q, v, a = iql.TwinQ(S, A).to(dev), iql.ValueFunction(S).to(dev), iql.GaussianPolicy(S, A, 1.0, dropout=0.0).to(dev)
+    learner = iql.ImplicitQLearning(
+        max_action=1.0, actor=a, actor_optimizer=torch.optim.Adam(a.parameters(), lr=meta["lrs"]["pi"]),
+        q_network=q, q_optimizer=torch.optim.Adam(q.parameters(), lr=meta["lrs"]["q"]),
+        v_network=v, v_optimizer=torch.optim.Adam(v.parameters(), lr=meta["lrs"]["v"]),
+        discount=hyper["discount"], tau=hyper["tau"], device=dev, beta=hyper["beta"], iql_tau=hyper["iql_tau"],
+        max_steps=None)
+    # get_learning_agent (jsrl_utils.py:350-355)
+    learner.partial_load_state_dict(guide.state_dict())
+    learner.total_it = meta["offline_iterations"]
+    assert learner.actor_lr_schedule is None and len(learner.q_optimizer.state) == 0
+    pg, pl = read_params(guide), read_params(learner)
+    for n in ("vf", "q1", "q2", "pi"):
+        for k in pg[n]:
+            assert np.array_equal(pg[n][k], pl[n][k]), (n, k)
+    for qn, tn in (("q1", "qt1"), ("q2", "qt2")):
+        for k in pl[qn]:
+            assert np.array_equal(pl[qn][k], pl[tn][k])
+    # the guide keeps training state of its own: the hand-off copied, it did not alias
+    assert learner._params_arena.data_ptr() != guide._params_arena.data_ptr()
+    one = synth.synth_transitions(1, S, A, seed=meta["row_seed"], antmaze_rewards=True)
+    ring = iql.ReplayBuffer(S, A, meta["buffer_size"], dev)
+    ring.add_transition(one["observations"][0], one["actions"][0], float(one["rewards"][0]), one["next_observations"][0],
+                        False)
+    np.random.seed(meta["np_seed"])
+    batch = ring.sample(B)
+    assert all(torch.equal(t[0], t[-1]) for t in batch)
+    log = learner.train(batch)
+    assert_losses(_losses(log), z["losses"], 1e-5)
+    check_step_against_golden(z, meta, None, read_params(learner), read_moments(learner), param_atol=2e-6,
+                              target_atol=1e-6)
+    assert learner.total_it == meta["total_it_after_step"]
+    # act() of the learner goes through the library and follows the loaded weights
+    s0 = one["observations"][0]
+    learner.actor.eval()
+    guide.actor.eval()
+    assert learner.actor.act(s0, dev).shape == (A,)
+
+
+def test_config3_ten_million_row_buffer():
+    """configs[3]'s buffer at its defining size (10 M rows x 176 B = 1.76 GB on one GPU): every row reachable, the
+    device index draw covers the whole range, and the chunked multi-step driver equals eager steps on it."""
+    import iql
+    import iqlhip_binding as hb
+    build, _, read_params, _, _ = _hip()
+    S, A, N, B = 17, 6, 10_000_000, 256
+    data = synth.synth_transitions(N, S, A, seed=0)
+    buf = iql.ReplayBuffer(S, A, N, "cuda")
+    buf.load_d4rl_dataset(data)
+    assert buf._size == N and buf._rows.shape == (N, 44)
+    probe = torch.tensor([0, 1, N // 2, N - 2, N - 1, 2_147_483_647 // 44 + 5], dtype=torch.int64, device="cuda")
+    s, a, r, ns, d = buf.gather(probe)          # (the last index: byte offset beyond 2^31 — 64-bit addressing)
+    idx = probe.cpu().numpy()
+    assert np.array_equal(s.cpu().numpy(), data["observations"][idx]) and np.array_equal(a.cpu().numpy(), data["actions"][idx])
+    assert np.array_equal(ns.cpu().numpy(), data["next_observations"][idx])
+    assert np.array_equal(r.cpu().numpy()[:, 0], data["rewards"][idx]) and np.array_equal(d.cpu().numpy()[:, 0], data["terminals"][idx])
+    n = 1 << 22
+    di = torch.empty(n, dtype=torch.int64, device="cuda")
+    hb.check(hb.lib().iqlhip_draw_indices(di.data_ptr(), n, N, 7, 0, torch.cuda.current_stream().cuda_stream))
+    assert int(di.min()) >= 0 and int(di.max()) < N and int(di.max()) > N - 100 and int(di.min()) < 100
+    params = synth.synth_params(S, A, seed=3)
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    K = 70
+    g = build(params, S, A, True, hyper, lrs, 1_000_000)
+    losses = g.train_steps(buf, K, B, seed=11)
+    e = build(params, S, A, True, hyper, lrs, 1_000_000)
+    ix = torch.empty(K * B, dtype=torch.int64, device="cuda")
+    hb.check(hb.lib().iqlhip_draw_indices(ix.data_ptr(), K * B, N, 11, 0, torch.cuda.current_stream().cuda_stream))
+    for k in range(K):
+        log = e.train(buf.gather(ix[k * B:(k + 1) * B]))
+        assert _losses(log) == [float(x) for x in losses[k]], k
+    pa, pb = read_params(g), read_params(e)
+    for nn in pa:
+        for kk in pa[nn]:
+            assert np.array_equal(pa[nn][kk], pb[nn][kk]), (nn, kk)
+    del buf, data
+    torch.cuda.empty_cache()
+
+
+def test_config5_share_fp32_and_bf16_against_reference_and_oracle():
+    """configs[4]'s per-GPU share (obs 39, act 28, 1024 rows, actor dropout 0.1 with injected masks): the fp32 path
+    against the reference fixture g14 at the usual tolerances; the bf16-operand path against the SAME fixture (losses
+    rel <= 2e-2, north_star's bf16 statement) and against the oracle's gradients (relative L2 per tensor <= 1e-1)."""
+    from oracle import iql_oracle as O
+    build, read_moments, read_params, to_tb, unflat = _hip()
+    z, meta = load_golden("g14_c5_B1024_dropout")
+    params, batch, hyper = single_step_inputs(meta)
+    p = meta["dropout"]
+    k0, k1 = synth.synth_dropout_keep(meta["B"], p, seed=meta["seed"])
+    masks = (k0.astype(np.float32) / np.float32(1.0 - p), k1.astype(np.float32) / np.float32(1.0 - p))
+    ref = O.iql_losses_and_grads(params, batch, hyper, actor_masks=masks)
+    tb = to_tb(batch)
+    # fp32
+    tr = build(params, meta["S"], meta["A"], True, hyper, meta["lrs"], meta["max_steps"], dropout=p)
+    tr.inject_dropout_masks(k0, k1)
+    grads, lw = unflat(tr, tr.flat_gradient(tb))
+    check_step_against_golden(z, meta, {"value_loss": lw[0], "q_loss": lw[1], "actor_loss": lw[2], "grads": grads},
+                              None, None, grad_rtol=3e-5, loss_rtol=1e-5)
+    log = tr.train(tb)
+    assert_losses(_losses(log), z["losses"], 1e-5)
+    check_step_against_golden(z, meta, None, read_params(tr), read_moments(tr), param_atol=2e-6, target_atol=1e-6)
+    # bf16 operands in the three 256-deep products
+    tb16 = build(params, meta["S"], meta["A"], True, hyper, meta["lrs"], meta["max_steps"], dropout=p)
+    tb16.set_precision("bf16")
+    tb16.inject_dropout_masks(k0, k1)
+    g16, l16 = unflat(tb16, tb16.flat_gradient(tb))
+    assert_losses(l16, z["losses"], 2e-2, "bf16 vs reference")
+    worst = 0.0
+    for net, tensors in ref["grads"].items():
+        for t, want in tensors.items():
+            got = g16[net][t].reshape(want.shape).astype(np.float64)
+            den = float(np.sqrt(np.sum(want.astype(np.float64) ** 2)))
+            if den < 1e-20:
+                continue
+            e = float(np.sqrt(np.sum((got - want) ** 2))) / den
+            worst = max(worst, e)
+            assert e <= 1e-1, (net, t, e)
+    log16 = tb16.train(tb)
+    assert_losses(_losses(log16), z["losses"], 2e-2, "bf16 step vs reference")
+    print("bf16 worst relative-L2 gradient error vs oracle:", worst)

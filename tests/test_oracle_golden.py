@@ -11,7 +11,8 @@ import pytest
 
 import synth
 from helpers import (ACT_CASES, FREERUN_CASES, SINGLE_STEP_CASES, act_case_params, assert_losses, batch_from,
-                     check_step_against_golden, load_golden, single_step_inputs, sub)
+                     check_state_against_golden, check_step_against_golden, load_golden, single_step_inputs, step_batch,
+                     sub)
 from oracle import iql_oracle as O
 
 
@@ -156,3 +157,81 @@ def test_actor_act_matches_reference(name):
         gn = O.actor_act(pi, z["states"], meta["max_action"], noise=z["noise"])
         assert np.max(np.abs(gn - z["actions_noise"])) <= 2e-6 * max(1.0, meta["max_action"])
         assert np.any(np.abs(gn) == meta["max_action"])        # the clamp is exercised (log_std[0] = 3 -> sigma = e^2)
+
+
+def _copy(tree):
+    return {n: {k: v.copy() for k, v in t.items()} for n, t in tree.items()}
+
+
+@pytest.mark.parametrize("name", ["g11_resume_S17A6_gauss", "g11_resume_S29A8_det"])
+def test_checkpoint_resume_matches_reference(name):
+    """G11: n steps -> state_dict -> load_state_dict into a fresh trainer -> one more step, as the reference ran it
+    (finetune/iql.py:565-593): after the load the target net is a COPY OF qf (the saved target is not in the
+    checkpoint), optimiser moments / step counts / the cosine schedule continue."""
+    z, meta = load_golden(name)
+    S, A, B, T = meta["S"], meta["A"], meta["B"], meta["max_steps"]
+    hyper = dict(meta["hyper"])
+    hyper["deterministic"] = not meta["gaussian"]
+    params = synth.synth_params(S, A, seed=meta["seed"], gaussian=meta["gaussian"])
+    opt = O.new_opt_state(params)
+    for k in range(meta["n_before"]):
+        lrs = dict(meta["lrs"], pi=O.cosine_lr(meta["lrs"]["pi"], k, T))
+        params, opt, info = O.iql_step(params, opt, step_batch(S, A, B, meta["batch_seed0"] + k), hyper, lrs)
+        assert_losses([info["value_loss"], info["q_loss"], info["actor_loss"]], z["losses_before"][k], 1e-5, f"step {k}")
+    check_state_against_golden(z, meta, "ckpt", params, opt, param_atol=4e-6, moment_rtol=3e-5, target_atol=1e-7)
+    assert abs(O.cosine_lr(meta["lrs"]["pi"], meta["n_before"], T) - float(z["ckpt.actor_lr"][0])) <= 1e-15
+    assert float(z["ckpt.q_step"][0]) == meta["n_before"] and meta["target_equals_qf_after_load"]
+    # the fresh trainer's own parameters are overwritten by the load; target := qf
+    loaded = _copy(params)
+    loaded["qt1"], loaded["qt2"] = _copy({"x": params["q1"]})["x"], _copy({"x": params["q2"]})["x"]
+    k = meta["n_before"]
+    lrs = dict(meta["lrs"], pi=O.cosine_lr(meta["lrs"]["pi"], k, T))
+    newp, newo, info = O.iql_step(loaded, opt, step_batch(S, A, B, meta["batch_seed0"] + k), hyper, lrs)
+    assert_losses([info["value_loss"], info["q_loss"], info["actor_loss"]], z["losses_after"], 1e-5, "after load")
+    check_state_against_golden(z, meta, "after", newp, newo, param_atol=4e-6, moment_rtol=3e-5, target_atol=1e-6)
+    assert meta["total_it_after"] == k + 1
+
+
+def test_jsrl_handoff_matches_reference():
+    """G12: the reference's own jsrl_utils.get_learning_agent (make_actor -> partial_load_state_dict(guide.state_dict())
+    -> total_it = offline_iterations, jsrl_utils.py:350-355) followed by the first online update, which samples 256
+    rows with replacement from a 10 000-row ring holding ONE row (jsrl_w_iql.py:540-548)."""
+    z, meta = load_golden("g12_jsrl_handoff_S29A8")
+    S, A, B = meta["S"], meta["A"], meta["B"]
+    hyper = dict(meta["hyper"], deterministic=False)
+    params = synth.synth_params(S, A, seed=meta["seed"])
+    opt = O.new_opt_state(params)
+    for k in range(2):       # the guide's offline steps (cosine schedule over offline_iterations)
+        lrs = dict(meta["lrs"], pi=O.cosine_lr(meta["lrs"]["pi"], k, meta["offline_iterations"]))
+        b = step_batch(S, A, B, meta["guide_batch_seed0"] + k, p_done=0.001, antmaze_rewards=True)
+        params, opt, info = O.iql_step(params, opt, b, hyper, lrs)
+        assert_losses([info["value_loss"], info["q_loss"], info["actor_loss"]], z["guide_losses"][k], 1e-5)
+    assert meta["total_it_after_handoff"] == meta["offline_iterations"] and not meta["learner_has_schedule"]
+    assert meta["learner_opt_state_len"] == 0 and meta["params_equal_guide"] and meta["target_equals_guide_qf"]
+    assert meta["all_curriculum_stages"] == [300.0] and meta["agent_type_stage"] == 1
+    # the learner: the guide's networks, target := qf, FRESH optimisers, constant learning rates
+    learner = _copy(params)
+    learner["qt1"], learner["qt2"] = _copy({"x": params["q1"]})["x"], _copy({"x": params["q2"]})["x"]
+    one = step_batch(S, A, 1, meta["row_seed"], antmaze_rewards=True)
+    one["d"][:] = 0.0                                   # add_transition(..., done=False)
+    np.random.seed(meta["np_seed"])
+    idx = np.random.randint(0, 1, size=B)               # size 1 ring: every index is 0
+    batch = {k: v[idx] for k, v in one.items()}
+    newp, newo, info = O.iql_step(learner, O.new_opt_state(learner), batch, hyper, meta["lrs"])
+    assert_losses([info["value_loss"], info["q_loss"], info["actor_loss"]], z["losses"], 1e-5)
+    check_step_against_golden(z, meta, {k: v for k, v in info.items() if k in ("value_loss", "q_loss", "actor_loss", "grads")},
+                              newp, newo, grad_rtol=3e-5, param_atol=2e-6, loss_rtol=1e-5, target_atol=1e-7)
+    assert meta["total_it_after_step"] == meta["offline_iterations"] + 1
+
+
+def test_config5_share_with_dropout_matches_reference():
+    """G14: configs[4]'s per-GPU share (obs 39, act 28, 1024 rows, actor dropout 0.1 by mask injection) in fp32."""
+    z, meta = load_golden("g14_c5_B1024_dropout")
+    params, batch, hyper = single_step_inputs(meta)
+    p = meta["dropout"]
+    k0, k1 = synth.synth_dropout_keep(meta["B"], p, seed=meta["seed"])
+    masks = (k0.astype(np.float32) / np.float32(1.0 - p), k1.astype(np.float32) / np.float32(1.0 - p))
+    newp, newo, info = O.iql_step(params, O.new_opt_state(params), batch, hyper, meta["lrs"], actor_masks=masks)
+    info2 = {k: v for k, v in info.items() if k not in ("next_v", "target_q", "adv")}
+    check_step_against_golden(z, meta, info2, newp, newo, grad_rtol=3e-5, param_atol=2e-6, loss_rtol=1e-5,
+                              target_atol=1e-7)

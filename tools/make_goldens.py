@@ -421,15 +421,204 @@ def act_case(ref, name, S, A, gaussian, max_action, seed, outdir, n=48):
     print(name, "ok; |a|max", float(np.abs(acts).max()))
 
 
+def import_reference_jsrl(ref_root: str):
+    """The reference's jsrl_utils.py (after import_reference: its `from iql import ...` binds the reference's iql)."""
+    def stub(name, **attrs):
+        if name in sys.modules:
+            return sys.modules[name]
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    pol = stub("stable_baselines3.sac.policies", Actor=_Any)
+    sac = stub("stable_baselines3.sac", policies=pol)
+    stub("stable_baselines3", SAC=_Any, sac=sac)
+    import jsrl_utils  # noqa: E402  (the reference module; sys.path already holds algorithms/finetune)
+    return jsrl_utils
+
+
+def _step_batch(S, A, B, seed):
+    return to_batch(synth.synth_transitions(B, S, A, seed=seed))
+
+
+def resume_case(ref, name, S, A, gaussian, seed, stride, outdir, n_before=3, B=256):
+    """G11: n_before steps -> state_dict() -> load_state_dict into a FRESH trainer (other initial
+    parameters) -> one more step.  Pins the checkpoint contents after training (params, moments, step counts, LR
+    schedule) and the continuation — incl. the reference's quirk that the target net is re-created as a copy of qf
+    (finetune/iql.py:581-593)."""
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    T = 50                                     # short cosine period: the restored scheduler state matters
+    tr = build_trainer(ref, S, A, synth.synth_params(S, A, seed=seed, gaussian=gaussian), gaussian, hyper, lrs, T)
+    losses = []
+    for k in range(n_before):
+        log = tr.train(_step_batch(S, A, B, 3000 + 10 * seed + k))
+        losses.append([log["value_loss"], log["q_loss"], log["actor_loss"]])
+    sd = tr.state_dict()
+    out = {f"ckpt.{k}": v for k, v in grab(tr, stride, gaussian).items() if not k.startswith("grad.")}
+    out["ckpt.actor_lr"] = np.array([tr.actor_optimizer.param_groups[0]["lr"]], dtype=np.float64)
+    out["ckpt.q_step"] = np.array([float(sd["q_optimizer"]["state"][0]["step"])])
+    tr2 = build_trainer(ref, S, A, synth.synth_params(S, A, seed=seed + 1, gaussian=gaussian), gaussian, hyper, lrs, T)
+    tr2.load_state_dict(sd)
+    same = all(torch.equal(a, b) for a, b in zip(tr2.q_target.parameters(), tr2.qf.parameters()))
+    log = tr2.train(_step_batch(S, A, B, 3000 + 10 * seed + n_before))
+    out.update({f"after.{k}": v for k, v in grab(tr2, stride, gaussian).items() if not k.startswith("grad.")})
+    out["losses_before"] = np.array(losses, dtype=np.float64)
+    out["losses_after"] = np.array([log["value_loss"], log["q_loss"], log["actor_loss"]], dtype=np.float64)
+    out["after.actor_lr"] = np.array([tr2.actor_optimizer.param_groups[0]["lr"]], dtype=np.float64)
+    meta = {"kind": "resume", "S": S, "A": A, "gaussian": gaussian, "B": B, "seed": seed, "stride": stride,
+            "hyper": hyper, "lrs": lrs, "max_steps": T, "n_before": n_before, "batch_seed0": 3000 + 10 * seed,
+            "target_equals_qf_after_load": bool(same), "total_it_after": int(tr2.total_it)}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez(os.path.join(outdir, name + ".npz"), **out)
+    print(f"{name}: before={losses[-1]} after={out['losses_after']}")
+
+
+class _JsrlCfg:
+    """The JsrlTrainConfig fields jsrl_utils.make_actor / get_learning_agent / prepare_finetuning read."""
+    device = "cpu"
+    actor_dropout = 0.0
+    iql_deterministic = False
+    vf_lr = qf_lr = actor_lr = 3e-4
+    discount, tau, beta, iql_tau = 0.99, 0.005, 10.0, 0.9          # antmaze values (configs[2])
+    n_curriculum_stages, horizon_fn, no_agent_types, rolling_mean_n, tolerance = 1, "time_step", True, 5, 0.05
+    guide_heuristic_fn = None
+    offline_iterations = 300
+    batch_size = 256
+
+
+def jsrl_handoff_case(ref, jsrl, name, S, A, seed, stride, outdir):
+    """G12: the offline -> online switch of the JSRL loop, run by the reference's own code:
+    guide trainer (2 offline steps) -> jsrl_utils.get_learning_agent (make_actor, partial_load_state_dict of the guide's
+    state_dict, total_it = offline_iterations; jsrl_utils.py:350-355) -> a fresh 10 000-row online buffer holding ONE
+    transition -> sample(256) (256 copies of that row: the update gate `t >= batch_size` counts global iterations,
+    jsrl_w_iql.py:540-548) -> train."""
+    cfg = _JsrlCfg()
+    hyper = {"iql_tau": cfg.iql_tau, "beta": cfg.beta, "discount": cfg.discount, "tau": cfg.tau}
+    lrs = {"v": cfg.vf_lr, "q": cfg.qf_lr, "pi": cfg.actor_lr}
+    guide = build_trainer(ref, S, A, synth.synth_params(S, A, seed=seed), True, hyper, lrs, cfg.offline_iterations)
+    g_losses = []
+    for k in range(2):
+        log = guide.train(to_batch(synth.synth_transitions(cfg.batch_size, S, A, seed=4000 + k, p_done=0.001,
+                                                           antmaze_rewards=True)))
+        g_losses.append([log["value_loss"], log["q_loss"], log["actor_loss"]])
+    torch.manual_seed(1234)        # make_actor's own random init is overwritten by the partial load (optimizers stay fresh)
+    import contextlib
+    import io
+    trainer, cfg2 = jsrl.get_learning_agent(cfg, guide, 300, S, A, 1.0)
+    desc = {"total_it_after_handoff": int(trainer.total_it), "learner_has_schedule": trainer.actor_lr_schedule is not None,
+            "learner_opt_state_len": len(trainer.q_optimizer.state),
+            "params_equal_guide": all(torch.equal(a, b) for a, b in zip(trainer.actor.parameters(), guide.actor.parameters())),
+            "target_equals_guide_qf": all(torch.equal(a, b) for a, b in zip(trainer.q_target.parameters(), guide.qf.parameters())),
+            "all_curriculum_stages": [float(x) for x in cfg2.all_curriculum_stages],
+            "agent_type_stage": float(cfg2.agent_type_stage)}
+    one = synth.synth_transitions(1, S, A, seed=4100, antmaze_rewards=True)
+    buf = ref.ReplayBuffer(S, A, 10_000, "cpu")
+    buf.add_transition(one["observations"][0], one["actions"][0], float(one["rewards"][0]), one["next_observations"][0],
+                       False)
+    np.random.seed(77)
+    batch = buf.sample(cfg.batch_size)
+    assert all(torch.equal(b[0], b[-1]) for b in batch)      # 256 copies of the one row
+    log = trainer.train(batch)
+    out = grab(trainer, stride, True)
+    out["guide_losses"] = np.array(g_losses, dtype=np.float64)
+    out["losses"] = np.array([log["value_loss"], log["q_loss"], log["actor_loss"]], dtype=np.float64)
+    desc["total_it_after_step"] = int(trainer.total_it)
+    meta = {"kind": "jsrl_handoff", "S": S, "A": A, "gaussian": True, "B": cfg.batch_size, "seed": seed, "stride": stride,
+            "hyper": hyper, "lrs": lrs, "offline_iterations": cfg.offline_iterations, "guide_batch_seed0": 4000,
+            "row_seed": 4100, "np_seed": 77, "buffer_size": 10_000, **desc}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez(os.path.join(outdir, name + ".npz"), **out)
+    print(f"{name}: handoff losses={out['losses']}")
+
+
+def jsrl_hostlogic_case(jsrl, outdir):
+    """SURVEY §8c "G9 JSRL host logic" (stored as g13: the g9_* names hold the dropout fixtures): prepare_finetuning's
+    curricula, a horizon_update_callback trace over a fixed evaluation sequence and timestep_horizon's truth table —
+    deterministic host logic of jsrl_utils.py:50-96, 137-174, 395-426 that must not change when `from iql import ...`
+    resolves to another module."""
+    import contextlib
+    import io
+
+    class Cfg(_JsrlCfg):
+        n_curriculum_stages = 5
+
+    out = {}
+    cfg = jsrl.prepare_finetuning(300, Cfg())
+    out["stages_time_step"] = np.asarray(cfg.all_curriculum_stages, dtype=np.float64)
+    out["agent_types_disabled"] = np.asarray(cfg.all_agent_types, dtype=np.float64)
+    c2 = Cfg()
+    c2.no_agent_types = False
+    c2.horizon_fn = "goal_dist"
+    c2 = jsrl.prepare_finetuning(12.5, c2)
+    out["stages_goal_dist"] = np.asarray(c2.all_curriculum_stages, dtype=np.float64)
+    out["agent_types_enabled"] = np.asarray(c2.all_agent_types, dtype=np.float64)
+    evals = [0.1, 0.2, 0.15, 0.3, 0.4, 0.1, 0.5, 0.6, 0.7, 0.65, 0.9, 0.95, 0.2, 0.99, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0,
+             1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+    trace = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for r in evals:
+            cfg = jsrl.horizon_update_callback(cfg, r)
+            trace.append([cfg.curriculum_stage_idx, cfg.curriculum_stage, cfg.agent_type_stage, cfg.best_eval_score,
+                          float(np.mean(cfg.rolling_mean_rews))])
+    out["evals"] = np.asarray(evals, dtype=np.float64)
+    out["callback_trace"] = np.asarray(trace, dtype=np.float64)
+    table = []
+    t = Cfg()
+    t = jsrl.prepare_finetuning(300, t)
+    for stage_idx in range(5):
+        t.curriculum_stage_idx = stage_idx
+        t.curriculum_stage = t.all_curriculum_stages[stage_idx]
+        for ep_type in (0.0, 1.0, 2.0):
+            t.ep_agent_type = ep_type
+            for step in (0, 74, 75, 150, 299, 300, 1000):
+                use, val = jsrl.timestep_horizon(step, None, None, t)
+                table.append([stage_idx, ep_type, step, float(use), float(val)])
+    t.curriculum_stage = np.nan
+    t.ep_agent_type = 5.0
+    use, val = jsrl.timestep_horizon(7, None, None, t)
+    table.append([-1, 5.0, 7, float(use), float(val)])
+    out["timestep_horizon_table"] = np.asarray(table, dtype=np.float64)
+    out["meta"] = np.array(json.dumps({"kind": "jsrl_host_logic", "init_horizon": 300, "n_curriculum_stages": 5,
+                                       "rolling_mean_n": 5, "tolerance": 0.05}))
+    np.savez(os.path.join(outdir, "g13_jsrl_hostlogic.npz"), **out)
+    print("g13_jsrl_hostlogic ok: final stage idx", trace[-1][0])
+
+
+def bf16_largebatch_case(ref, name, outdir, stride=13):
+    """configs[4]'s per-GPU share in fp32 BY THE REFERENCE (S=39, A=28, B=1024, actor dropout 0.1 with injected masks,
+    iql_tau 0.8): the oracle target of the bf16-operand path at its defining size."""
+    dropout_case(ref, name, 39, 28, True, 0.1, 1024, 82, stride, outdir)
+
+
+def round2_cases(ref, args):
+    jsrl = import_reference_jsrl(args.ref)
+    resume_case(ref, "g11_resume_S17A6_gauss", 17, 6, True, 110, 13, args.out)
+    resume_case(ref, "g11_resume_S29A8_det", 29, 8, False, 112, 13, args.out)
+    jsrl_handoff_case(ref, jsrl, "g12_jsrl_handoff_S29A8", 29, 8, 120, 13, args.out)
+    jsrl_hostlogic_case(jsrl, args.out)
+    bf16_largebatch_case(ref, "g14_c5_B1024_dropout", args.out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default=None, help="generate only the G10 act fixtures ('act')")
+    ap.add_argument("--only", default=None, help="'act': only the G10 act fixtures; 'r2': only the round-2 fixtures "
+                                                 "(g11 resume, g12 JSRL hand-off, g13 JSRL host logic, g14 config-5 batch)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(1)
     ref = import_reference(args.ref)
+    if args.only == "r2":
+        round2_cases(ref, args)
+        return
 
     act_case(ref, "g10_act_S17A6_gauss", 17, 6, True, 1.0, 90, args.out)
     act_case(ref, "g10_act_S29A8_det", 29, 8, False, 2.5, 91, args.out)
@@ -456,6 +645,7 @@ def main():
     ring_case(ref, args.out)
     lr_case(ref, args.out)
     statedict_case(ref, args.out)
+    round2_cases(ref, args)
 
 
 if __name__ == "__main__":
