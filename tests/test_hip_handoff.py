@@ -36,7 +36,8 @@ def test_checkpoint_of_gpu_trained_trainer_resumes_like_the_reference(name, tmp_
         log = tr.train(to_tb(step_batch(S, A, B, meta["batch_seed0"] + k)))
         assert_losses(_losses(log), z["losses_before"][k], 1e-5, f"step {k}")
     sd = tr.state_dict()
-    check_state_against_golden(z, meta, "ckpt", read_params(tr), read_moments(tr), param_atol=4e-6, moment_rtol=3e-5)
+    w1 = check_state_against_golden(z, meta, "ckpt", read_params(tr), read_moments(tr), param_atol=2e-6, moment_rtol=1e-5)
+    print(name, "ckpt worst:", {k: max(v for kk, v in w1.items() if f".{k}." in kk) for k in ("param", "m", "v")})
     assert float(sd["q_optimizer"]["state"][0]["step"]) == float(z["ckpt.q_step"][0]) == meta["n_before"]
     assert sd["total_it"] == meta["n_before"]
     assert abs(sd["actor_optimizer"]["param_groups"][0]["lr"] - float(z["ckpt.actor_lr"][0])) <= 1e-18
@@ -61,8 +62,11 @@ def test_checkpoint_of_gpu_trained_trainer_resumes_like_the_reference(name, tmp_
                 assert np.array_equal(ma[mv][n][k], mb[mv][n][k]), (mv, n, k)
     log = fresh.train(to_tb(step_batch(S, A, B, meta["batch_seed0"] + meta["n_before"])))
     assert_losses(_losses(log), z["losses_after"], 1e-5, "after load")
-    check_state_against_golden(z, meta, "after", read_params(fresh), read_moments(fresh), param_atol=4e-6,
-                               moment_rtol=3e-5, target_atol=1e-6)
+    w2 = check_state_against_golden(z, meta, "after", read_params(fresh), read_moments(fresh), param_atol=2e-6,
+                                    moment_rtol=1e-5, target_atol=5e-7)   # (target := qf at the load: it inherits
+    # qf's Adam-amplified differences, observed 1.1e-7, instead of the 1e-7 of a Polyak-only history)
+    print(name, "after worst:", {k: max(v for kk, v in w2.items() if f".{k}." in kk) for k in ("param", "m", "v")},
+          "target:", max(v for kk, v in w2.items() if ".qt" in kk))
     assert abs(fresh.actor_optimizer.param_groups[0]["lr"] - float(z["after.actor_lr"][0])) <= 1e-18
     assert fresh.total_it == meta["total_it_after"]
     # the graph path continues from a loaded checkpoint as well (arenas, step counts and schedule are all live)
@@ -122,7 +126,7 @@ def test_jsrl_handoff_on_arena_backed_trainers_matches_reference():
     log = learner.train(batch)
     assert_losses(_losses(log), z["losses"], 1e-5)
     check_step_against_golden(z, meta, None, read_params(learner), read_moments(learner), param_atol=2e-6,
-                              target_atol=1e-6)
+                              moment_rtol=1e-5, target_atol=1e-7)
     assert learner.total_it == meta["total_it_after_step"]
     # act() of the learner goes through the library and follows the loaded weights
     s0 = one["observations"][0]
@@ -142,8 +146,9 @@ def test_config3_ten_million_row_buffer():
     buf = iql.ReplayBuffer(S, A, N, "cuda")
     buf.load_d4rl_dataset(data)
     assert buf._size == N and buf._rows.shape == (N, 44)
-    probe = torch.tensor([0, 1, N // 2, N - 2, N - 1, 2_147_483_647 // 44 + 5], dtype=torch.int64, device="cuda")
-    s, a, r, ns, d = buf.gather(probe)          # (the last index: byte offset beyond 2^31 — 64-bit addressing)
+    probe = torch.tensor([0, 1, N // 2, N - 2, N - 1], dtype=torch.int64, device="cuda")
+    assert int(probe.max()) < N
+    s, a, r, ns, d = buf.gather(probe)
     idx = probe.cpu().numpy()
     assert np.array_equal(s.cpu().numpy(), data["observations"][idx]) and np.array_equal(a.cpu().numpy(), data["actions"][idx])
     assert np.array_equal(ns.cpu().numpy(), data["next_observations"][idx])
@@ -190,10 +195,11 @@ def test_config5_share_fp32_and_bf16_against_reference_and_oracle():
     tr.inject_dropout_masks(k0, k1)
     grads, lw = unflat(tr, tr.flat_gradient(tb))
     check_step_against_golden(z, meta, {"value_loss": lw[0], "q_loss": lw[1], "actor_loss": lw[2], "grads": grads},
-                              None, None, grad_rtol=3e-5, loss_rtol=1e-5)
+                              None, None, grad_rtol=1e-5, loss_rtol=1e-5)
     log = tr.train(tb)
     assert_losses(_losses(log), z["losses"], 1e-5)
-    check_step_against_golden(z, meta, None, read_params(tr), read_moments(tr), param_atol=2e-6, target_atol=1e-6)
+    check_step_against_golden(z, meta, None, read_params(tr), read_moments(tr), param_atol=2e-6, moment_rtol=1e-5,
+                              target_atol=1e-7)
     # bf16 operands in the three 256-deep products
     tb16 = build(params, meta["S"], meta["A"], True, hyper, meta["lrs"], meta["max_steps"], dropout=p)
     tb16.set_precision("bf16")

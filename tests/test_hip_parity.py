@@ -1,10 +1,12 @@
 """GPU parity tests: the HIP step (through the C ABI, via the drop-in Python surface)
 against (i) the committed reference-generated goldens and (ii) the oracle on the
 same seeded inputs.  Tolerances are SURVEY.md §8(d)'s teacher-forced single-step
-protocol: losses rel <= 1e-5, gradients rel-to-max <= 3e-5 (fp32 summation-order
-noise on cancelling sums; the oracle itself sits at 1.1e-5 from the reference on one
-tensor), post-step parameters abs <= 2e-6, Adam moments rel-to-max <= 5e-5, target
-abs <= 1e-7*scale.
+protocol, set from the observed margins in profiles/r02_parity_margins.txt
+(tools/gpu_parity_report.py): losses rel <= 1e-5 (observed 2e-7), gradients
+|dg|inf <= 1e-5 * |g|inf per tensor (observed 2.6e-6; stricter than SURVEY's
+1e-5 * max(1, |g|inf)), post-step parameters abs <= 2e-6 (observed 1.5e-8) plus Adam's
+documented amplification for elements whose gradient is within noise of eps, Adam
+moments rel-to-max <= 1e-5 (observed 5.4e-6), target abs <= 1e-7 (observed 2.6e-8).
 """
 import os
 
@@ -40,12 +42,12 @@ def test_single_step_matches_reference_golden(name):
     tq = np.minimum(hv["qt1"], hv["qt2"])
     info = {"value_loss": lw[0], "q_loss": lw[1], "actor_loss": lw[2], "next_v": hv["next_v"],
             "target_q": tq, "adv": tq - hv["v"], "grads": grads}
-    check_step_against_golden(z, meta, info, None, None, grad_rtol=3e-5, loss_rtol=1e-5)
+    check_step_against_golden(z, meta, info, None, None, grad_rtol=1e-5, loss_rtol=1e-5)
     log = tr.train(tb)
     assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"], 1e-5)
     assert tr.total_it == 1
     check_step_against_golden(z, meta, None, read_params(tr), read_moments(tr), param_atol=2e-6,
-                              target_atol=1e-6)
+                              moment_rtol=1e-5, target_atol=1e-7)
     # the cosine schedule advanced exactly like the reference's
     assert abs(tr.actor_optimizer.param_groups[0]["lr"] - float(z["lr_after"][0])) < 1e-18
 
@@ -286,10 +288,11 @@ def test_dropout_step_with_injected_masks_matches_reference(name):
     tb = to_tb(batch)
     grads, lw = unflat(tr, tr.flat_gradient(tb))
     info = {"value_loss": lw[0], "q_loss": lw[1], "actor_loss": lw[2], "grads": grads}
-    check_step_against_golden(z, meta, info, None, None, grad_rtol=3e-5, loss_rtol=1e-5)
+    check_step_against_golden(z, meta, info, None, None, grad_rtol=1e-5, loss_rtol=1e-5)
     log = tr.train(tb)
     assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"], 1e-5)
-    check_step_against_golden(z, meta, None, read_params(tr), read_moments(tr), param_atol=2e-6, target_atol=1e-6)
+    check_step_against_golden(z, meta, None, read_params(tr), read_moments(tr), param_atol=2e-6, moment_rtol=1e-5,
+                              target_atol=1e-7)
 
 
 def test_dropout_device_masks_statistics_and_eval_mode():
@@ -429,21 +432,28 @@ def test_edge_shapes_match_oracle(S, A, B, gaussian):
     lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
     tr = build(params, S, A, gaussian, hyper, lrs, 1000)
     newp, newo, info = O.iql_step(params, O.new_opt_state(params), batch, hyper, lrs)
+    # losses and gradients against the oracle evaluated in float64 (two fp32 evaluations of a cancelling sum can each
+    # sit 1e-5 from the truth; against the float64 value the fp32 kernels hold north_star's 1e-5 on the losses and
+    # SURVEY §8d's |dg|inf <= 1e-5 * max(1, |g|inf) on every gradient tensor)
+    i64 = O.iql_losses_and_grads(params, batch, hyper, dtype=np.float64)
+    want_l = [i64["value_loss"], i64["q_loss"], i64["actor_loss"]]
     grads, lw = unflat(tr, tr.flat_gradient(to_tb(batch)))
-    assert_losses(lw, [info["value_loss"], info["q_loss"], info["actor_loss"]], 2e-5)
+    assert_losses(lw, want_l, 1e-5)
     for n, t in grads.items():
         for k, g in t.items():
-            want = info["grads"][n][k]
-            assert np.max(np.abs(g - want)) <= 5e-5 * max(np.max(np.abs(want)), 1e-30), (n, k)
+            want = i64["grads"][n][k]
+            gmax = float(np.max(np.abs(want)))
+            err = float(np.max(np.abs(g.astype(np.float64) - want)))
+            assert err <= 1e-5 * max(1.0, gmax), (n, k, err, gmax)
+            assert err <= 2e-5 * max(gmax, 1e-30), (n, k, err / max(gmax, 1e-30))    # and relative to the tensor's own max
     log = tr.train(to_tb(batch))
-    assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]],
-                  [info["value_loss"], info["q_loss"], info["actor_loss"]], 2e-5)
+    assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], want_l, 1e-5)
     got = read_params(tr)
     for n, t in got.items():
         for k, p in t.items():
             diff = np.abs(p - newp[n][k])
             if n in ("qt1", "qt2"):
-                assert diff.max() <= 1e-6, (n, k)
+                assert diff.max() <= 1e-7, (n, k)
             else:   # Adam amplifies rounding of near-eps gradients: allow it exactly there (see helpers.py)
                 gref = np.abs(info["grads"][n][k])
                 tol = 2e-6 + 3e-4 * np.minimum(1.0, 1e-8 * (2e-6 * max(gref.max(), 1e-30)) / (gref + 1e-8) ** 2)
