@@ -149,6 +149,15 @@ int iqlhip_bind(iqlhip_ctx* ctx, float* params_dev, float* target_dev, float* ex
  * three groups; Polyak.  Losses land in device words read by iqlhip_read_losses. */
 int iqlhip_step(iqlhip_ctx* ctx, const iqlhip_batch* batch, const iqlhip_step_scalars* sc, void* stream);
 
+/* One iteration of the online fine-tuning loop's device work (algorithms/finetune/iql.py:741-773, jsrl_w_iql.py:
+ * 512-548: add_transition -> sample -> train) in one call: the new packed transition row_host[ld] is stored at ring
+ * row `pointer` of rows_dev (capacity rows), the batch rows_dev[idx_host[0..n)] (indices as np.random.randint drew them,
+ * AFTER the insert, iql.py:172) is gathered and one IQL step runs on it.  row_host / idx_host are ordinary host
+ * memory (copied into pinned staging inside the call).  Synchronous: returns the three losses in out[3]. */
+int iqlhip_online_step(iqlhip_ctx* ctx, float* rows_dev, int64_t ld, int64_t capacity, int64_t pointer,
+                       const float* row_host, const int64_t* idx_host, int32_t n, const iqlhip_step_scalars* sc,
+                       float out[3], void* stream);
+
 /* Data-parallel split of the same step: forward+backward, then the
  * flat gradient (n_params floats + 4 tail words: 3 loss sums and a spare) is
  * written to grads_dev for the caller's all-reduce, then the update consumes it. */
@@ -233,6 +242,16 @@ int iqlhip_rows_gather_packed_h(const float* rows_dev, int64_t ld, const int64_t
  * device side of ReplayBuffer.sample(batch_size) after the np.random.randint draw, in one call. */
 int iqlhip_rows_sample_packed(const float* rows_dev, int64_t ld, const int64_t* idx_host, int64_t n,
                               float* out_rows_dev, void* stream);
+/* ---- dataset ingest on the device -------------------------------------------------------------
+ * compute_mean_std (algorithms/finetune/iql.py:77-80): mean[c] = mean_r x[r][c], std[c] = sqrt(mean_r (x - mean)^2) + eps
+ * over n rows of ncols columns (row stride ld floats; e.g. the state columns of packed replay rows: x = rows_dev,
+ * ncols = state_dim).  Sums in float64, fixed order (deterministic); results are float32 like numpy's. */
+int iqlhip_cols_mean_std(const float* x_dev, int64_t ld, int32_t ncols, int64_t n, float eps, float* mean_dev,
+                         float* std_dev, void* stream);
+/* normalize_states (:83-84) applied in place to the s and s' columns of n packed rows from row0:
+ * x = (x - mean[c]) / std[c] in fp32 — bit-identical to numpy given the same mean / std. */
+int iqlhip_rows_normalize(float* rows_dev, int64_t ld, int32_t state_dim, int32_t action_dim, int64_t row0, int64_t n,
+                          const float* mean_dev, const float* std_dev, void* stream);
 /* Device-side index draw used by iqlhip_train_steps, exposed for tests. */
 int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, uint64_t seed, uint64_t offset, void* stream);
 

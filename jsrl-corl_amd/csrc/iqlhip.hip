@@ -93,6 +93,9 @@ struct iqlhip_ctx {
   float* xb_act = nullptr;            // [act_cap][row_ld]
   float* heads_act = nullptr;         // [act_cap][A][NSPLIT]
   float* losses_host = nullptr;       // pinned landing pad of read_losses (a pageable D2H goes through a bounce copy)
+  float* on_row_pin = nullptr;        // iqlhip_online_step: pinned, host-mapped staging of the new transition [row_ld]
+  long long* on_idx_pin = nullptr;    // ... and of the sampled indices [max_batch]
+  float* on_loss_pin = nullptr;       // ... and the landing words of the step's three losses [4]
   int act_cap = 0;
   unsigned long long act_calls = 0;   // Philox call counter of iqlhip_actor_sample
   int64_t row_ld = 0;
@@ -216,6 +219,9 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   HIPCHK(dalloc(&c->xb, (size_t)MB * c->row_ld));
   HIPCHK(dalloc(&c->xb2, (size_t)MB * c->row_ld));
   HIPCHK(hipHostMalloc((void**)&c->losses_host, 4 * sizeof(float), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&c->on_row_pin, (size_t)c->row_ld * sizeof(float), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&c->on_idx_pin, (size_t)MB * sizeof(long long), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&c->on_loss_pin, 4 * sizeof(float), hipHostMallocDefault));
   c->act_cap = std::max(MB, IQLHIP_ACT_ROWS);
   HIPCHK(dalloc(&c->xb_act, (size_t)c->act_cap * c->row_ld));
   HIPCHK(dalloc(&c->heads_act, (size_t)c->act_cap * A * NSPLIT));
@@ -331,6 +337,9 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
     if (c->sched_done[i]) (void)hipEventDestroy(c->sched_done[i]);
   }
   if (c->losses_host) (void)hipHostFree(c->losses_host);
+  if (c->on_row_pin) (void)hipHostFree(c->on_row_pin);
+  if (c->on_idx_pin) (void)hipHostFree(c->on_idx_pin);
+  if (c->on_loss_pin) (void)hipHostFree(c->on_loss_pin);
   delete c;
   return IQLHIP_OK;
 }
@@ -501,6 +510,7 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.flat_grads = flat;
   u.loss_parts = c->sc.loss_parts;
   u.losses = c->sc.losses;
+  u.losses_mirror = nullptr;
   u.loss_ring = nullptr;
   u.ring_slot = 0;
   u.n_chunk = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
@@ -838,6 +848,40 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   return IQLHIP_OK;
 }
 
+// One iteration of the online loop's device work (algorithms/finetune/iql.py:741-773: add_transition -> sample ->
+// train) in ONE call and four launches: ring write + gather straight from pinned host words, forward, backward, update
+// with the losses landing in pinned host words; then one stream synchronisation.
+extern "C" int iqlhip_online_step(iqlhip_ctx* c, float* rows_dev, int64_t ld, int64_t capacity, int64_t pointer,
+                                  const float* row_host, const int64_t* idx_host, int32_t n,
+                                  const iqlhip_step_scalars* sc, float out[3], void* stream) {
+  if (!c || !rows_dev || !row_host || !idx_host || !sc || !out) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (!c->params) return fail(IQLHIP_ENOTBOUND, "iqlhip_bind has not been called");
+  if (ld != c->row_ld) return fail(IQLHIP_EINVAL, "row stride must be iqlhip_row_stride(S,A)=%lld", (long long)c->row_ld);
+  if (((uintptr_t)rows_dev) & 15) return fail(IQLHIP_EINVAL, "packed rows must be 16-byte aligned");
+  if (n < 1 || n > c->dims.max_batch) return fail(IQLHIP_EINVAL, "batch rows %d outside [1, max_batch=%d]", n, c->dims.max_batch);
+  if (capacity < 1 || pointer < 0 || pointer >= capacity) return fail(IQLHIP_EINVAL, "ring pointer outside the buffer");
+  for (int i = 0; i < n; ++i)             // (the reference's torch indexing raises on such an index; a gather would fault)
+    if (idx_host[i] < 0 || idx_host[i] >= capacity) return fail(IQLHIP_EINVAL, "sampled index %lld outside the buffer", (long long)idx_host[i]);
+  DevGuard guard(c->device);
+  hipStream_t st = (hipStream_t)stream;
+  memcpy(c->on_row_pin, row_host, (size_t)ld * sizeof(float));
+  memcpy(c->on_idx_pin, idx_host, (size_t)n * sizeof(long long));
+  const int total = n * (int)(ld / 4);
+  hipLaunchKernelGGL(iql_online_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, st, rows_dev, (long long)ld,
+                     (long long)pointer, (const float*)c->on_row_pin, (const long long*)c->on_idx_pin, c->xb, n);
+  if (c->drop_p > 0.f && !c->drop_inject) launch_dropmask(c, c->drop_seed, c->drop_step++, nullptr, 0, st);
+  StepParams p = make_step(c, n, sc->inv_batch);
+  UpdParams u = make_upd(c, sc, n, nullptr);
+  u.losses_mirror = c->on_loss_pin;
+  int rc = enqueue_step(c, p, u, c->xch_mode, (int)(c->xstep & 1ull), 0, /*from_hdr=*/false, st, nullptr);
+  if (rc) return rc;
+  if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += 1;
+  HIPCHK(hipStreamSynchronize(st));        // (a synchronous call: the pinned staging words are free again on return)
+  out[0] = c->on_loss_pin[0]; out[1] = c->on_loss_pin[1]; out[2] = c->on_loss_pin[2];
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
 extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_scalars* sc,
                                        float* grads_dev, void* stream) {
   if (!c || !sc || !grads_dev) return fail(IQLHIP_EINVAL, "NULL argument");
@@ -1137,6 +1181,43 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
     c->t_acc[3] += ms * 1e3f;   // total per call; per-step = /K done by the caller
     c->t_n += 1;
   }
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Dataset ingest on the device.
+extern "C" int iqlhip_cols_mean_std(const float* x_dev, int64_t ld, int32_t ncols, int64_t n, float eps, float* mean_dev,
+                                    float* std_dev, void* stream) {
+  if (!x_dev || !mean_dev || !std_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (ncols < 1 || ncols > 4096 || n < 1 || ld < ncols) return fail(IQLHIP_EINVAL, "bad cols_mean_std geometry");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)std::min<int64_t>((n + 7) / 8, MS_BLOCKS);
+  double* scratch = nullptr;                         // [nb][ncols] partials + [ncols] float64 means
+  HIPCHK(hipMallocAsync((void**)&scratch, ((size_t)nb * ncols + ncols) * sizeof(double), st));
+  double* mean64 = scratch + (size_t)nb * ncols;
+  hipLaunchKernelGGL(iql_cols_moment_kernel<0>, dim3(nb), dim3(256), 0, st, x_dev, (long long)ld, ncols, (long long)n,
+                     (const double*)nullptr, scratch);
+  hipLaunchKernelGGL(iql_cols_finish_kernel<0>, dim3((ncols + 63) / 64), dim3(64), 0, st, (const double*)scratch, nb, ncols,
+                     (long long)n, eps, mean64, mean_dev);
+  hipLaunchKernelGGL(iql_cols_moment_kernel<1>, dim3(nb), dim3(256), 0, st, x_dev, (long long)ld, ncols, (long long)n,
+                     (const double*)mean64, scratch);
+  hipLaunchKernelGGL(iql_cols_finish_kernel<1>, dim3((ncols + 63) / 64), dim3(64), 0, st, (const double*)scratch, nb, ncols,
+                     (long long)n, eps, mean64, std_dev);
+  HIPCHK(hipFreeAsync(scratch, st));
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+extern "C" int iqlhip_rows_normalize(float* rows_dev, int64_t ld, int32_t S, int32_t A, int64_t row0, int64_t n,
+                                     const float* mean_dev, const float* std_dev, void* stream) {
+  if (!rows_dev || !mean_dev || !std_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (n < 0 || row0 < 0 || S < 1 || A < 1 || ld < 2 * (int64_t)S + A + 2) return fail(IQLHIP_EINVAL, "bad rows_normalize geometry");
+  if (n == 0) return IQLHIP_OK;
+  const long long total = (long long)n * 2 * S;
+  const int nb = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(iql_rows_normalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows_dev, (long long)ld, S, A,
+                     (long long)row0, (long long)n, mean_dev, std_dev);
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }

@@ -1457,6 +1457,7 @@ struct UpdParams {
   int n_peer;
   float* loss_parts;
   float* losses;            // [4]
+  float* losses_mirror;     // nullable: second copy of the three losses (host-mapped pinned words: iqlhip_online_step)
   float* loss_ring;         // nullable
   int ring_slot;
   int n_chunk, n_rt;
@@ -1763,6 +1764,7 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
       l[2] = s[3] * ib;                         // mean(exp_adv * bc)                 iql.py:534
     }
     u.losses[0] = l[0]; u.losses[1] = l[1]; u.losses[2] = l[2];
+    if (u.losses_mirror) { u.losses_mirror[0] = l[0]; u.losses_mirror[1] = l[1]; u.losses_mirror[2] = l[2]; }
     if (u.loss_ring) {
       const long long slot = (long long)u.ring_slot + (u.ring_hdr ? (long long)u.ring_hdr[HDR_BASE] : 0ll);
       float* rr = u.loss_ring + 4 * slot;
@@ -1936,5 +1938,95 @@ __global__ void iql_draw_indices_kernel(long long* idx, long long n, long long s
     const unsigned long long r1 = ((unsigned long long)c[3] << 32) | c[2];
     idx[2 * i] = (long long)__umul64hi(r0, (unsigned long long)size);
     if (2 * i + 1 < n) idx[2 * i + 1] = (long long)__umul64hi(r1, (unsigned long long)size);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Dataset ingest: column mean / std of n rows (compute_mean_std, algorithms/finetune/iql.py:77-80:
+// mean = x.mean(0), std = x.std(0) + eps, population variance) and the in-place normalisation of the state columns of
+// packed rows (normalize_states, :83-84: (x - mean) / std in fp32, IEEE division).  Sums are kept in float64 and
+// combined in a fixed order (block partials, then one thread per column): deterministic, and closer to the exact
+// value than numpy's float32 pairwise sums — the parity statement is therefore a tolerance against numpy
+// (tests: rel <= 1e-6 against a float64 numpy evaluation, <= 2e-5 against numpy's own float32 result).
+#define MS_BLOCKS 512
+// pass 0: partial[b][c] = sum over the block's rows of x[r][c];  pass 1: sum of (x - mean[c])^2
+template <int PASS>
+__global__ __launch_bounds__(256) void iql_cols_moment_kernel(const float* x, long long ld, int ncols, long long n,
+                                                              const double* mean, double* partial) {
+  __shared__ double red[8][33];
+  const int c_lane = threadIdx.x & 31, r_lane = threadIdx.x >> 5;     // 8 rows x 32 columns per pass
+  for (int c0 = 0; c0 < ncols; c0 += 32) {
+    const int c = c0 + c_lane;
+    double acc = 0.0;
+    if (c < ncols) {
+      const double mu = PASS ? mean[c] : 0.0;
+      for (long long r = (long long)blockIdx.x * 8 + r_lane; r < n; r += (long long)gridDim.x * 8) {
+        const double v = (double)x[r * ld + c];
+        acc += PASS ? (v - mu) * (v - mu) : v;
+      }
+    }
+    red[r_lane][c_lane] = acc;
+    __syncthreads();
+    if (r_lane == 0 && c < ncols) {
+      double s = red[0][c_lane];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) s += red[k][c_lane];
+      partial[(long long)blockIdx.x * ncols + c] = s;
+    }
+    __syncthreads();
+  }
+}
+// one thread per column: fixed-order sum of the block partials -> mean (pass 0) or std + eps (pass 1)
+template <int PASS>
+__global__ void iql_cols_finish_kernel(const double* partial, int nblocks, int ncols, long long n, float eps,
+                                       double* mean64, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * ncols + c];
+  if (PASS == 0) {
+    mean64[c] = s / (double)n;
+    out[c] = (float)(s / (double)n);
+  } else {
+    out[c] = (float)sqrt(s / (double)n) + eps;       // np.std(float32 array) returns float32, then + eps in float32
+  }
+}
+
+__global__ void iql_rows_normalize_kernel(float* rows, long long ld, int S, int A, long long row0, long long n,
+                                          const float* mean, const float* stdv) {
+  const long long total = n * 2 * S;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / (2 * S);
+    const int c2 = (int)(e - i * 2 * S);
+    const int c = (c2 < S) ? c2 : c2 - S;
+    float* p = rows + (row0 + i) * ld + ((c2 < S) ? c : S + A + c);
+    *p = (*p - mean[c]) / stdv[c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// One online iteration's buffer work in one launch (iqlhip_online_step): the new transition `row_host` (pinned,
+// host-mapped, ld floats) is stored at ring row `pointer`, and the batch rows[idx_host[r]] (indices in pinned,
+// host-mapped memory, exactly as np.random.randint drew them) are gathered into xb.  A sampled index equal to
+// `pointer` reads the new row from `row_host` itself — the ring write of block 0 may not have happened yet.
+__global__ __launch_bounds__(256) void iql_online_gather_kernel(float* rows, long long ld, long long pointer,
+                                                                const float* row_host, const long long* idx_host,
+                                                                float* xb, int n) {
+  __shared__ long long s_idx[260];
+  const int q = (int)(ld >> 2);
+  const int e0 = (int)blockIdx.x * 256;
+  const int r_first = e0 / q;
+  const int r_last = min((e0 + 255) / q, n - 1);
+  if ((int)threadIdx.x <= r_last - r_first) s_idx[threadIdx.x] = idx_host[r_first + threadIdx.x];
+  if (blockIdx.x == 0 && (int)threadIdx.x < q)
+    *(f32x4*)(rows + pointer * ld + 4 * threadIdx.x) = *(const f32x4*)(row_host + 4 * threadIdx.x);
+  __syncthreads();
+  const int e = e0 + (int)threadIdx.x;
+  if (e < n * q) {
+    const int r = e / q, c4 = e - r * q;
+    const long long i = s_idx[r - r_first];
+    const float* src = (i == pointer) ? row_host : rows + i * ld;
+    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = *(const f32x4*)(src + 4 * c4);
   }
 }

@@ -76,6 +76,8 @@ SYMBOLS = [
     ("iqlhip_set_dropout", C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
     ("iqlhip_debug_write_masks", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("iqlhip_step", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(StepScalars), C.c_void_p]),
+    ("iqlhip_online_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.POINTER(StepScalars), C.POINTER(C.c_float), C.c_void_p]),
     ("iqlhip_forward_backward", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(StepScalars), C.c_void_p, C.c_void_p]),
     ("iqlhip_apply_update", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StepScalars), C.c_void_p]),
     ("iqlhip_grad_words", C.c_int64, [C.c_void_p]),
@@ -105,6 +107,10 @@ SYMBOLS = [
     ("iqlhip_rows_gather_packed_h", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                               C.c_void_p]),
     ("iqlhip_rows_sample_packed", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("iqlhip_cols_mean_std", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    ("iqlhip_rows_normalize", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     ("iqlhip_draw_indices", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
     ("iqlhip_debug_read", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]),

@@ -92,10 +92,12 @@ def _hip_owner(actor: nn.Module, device) -> Optional[object]:
 
 
 class _PolicyBase(nn.Module):
+    _MLP = MLP          # the offline flavour (iqlhip_offline.py) substitutes its MLP (other dropout gate)
+
     def __init__(self, state_dim: int, act_dim: int, max_action: float, hidden_dim: int, n_hidden: int, dropout):
         super().__init__()
-        self.net = MLP([state_dim] + [hidden_dim] * n_hidden + [act_dim], output_activation_fn=nn.Tanh,
-                       dropout=dropout)
+        self.net = self._MLP([state_dim] + [hidden_dim] * n_hidden + [act_dim], output_activation_fn=nn.Tanh,
+                             dropout=dropout)
         self.max_action = max_action
 
     def _scaled(self, action: torch.Tensor) -> np.ndarray:

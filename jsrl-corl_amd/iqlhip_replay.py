@@ -114,6 +114,31 @@ class ReplayBuffer:
         self._pointer = min(self._size, n_transitions)
         print(f"Dataset size: {n_transitions}")
 
+    # ---- dataset ingest on the device (not part of the reference's surface) -------------------
+    def state_mean_std(self, eps: float = 1e-3):
+        """compute_mean_std (iql.py:77-80) of the stored `observations` column block, reduced on the device:
+        (mean, std + eps) as float32 numpy arrays [state_dim]."""
+        import iqlhip_ingest as ing
+        if not self._gpu:
+            raise RuntimeError("iqlhip: state_mean_std runs in libiqlhip.so and needs a GPU buffer")
+        if self._size < 1:
+            raise ValueError("replay buffer is empty")
+        mean, std = ing.cols_mean_std(self._rows[: self._size, : self._state_dim], eps)
+        return mean.cpu().numpy(), std.cpu().numpy()
+
+    def normalize_states_(self, mean: np.ndarray, std: np.ndarray) -> None:
+        """normalize_states (iql.py:83-84) applied IN PLACE to the s and s' columns of every stored row."""
+        if not self._gpu:
+            raise RuntimeError("iqlhip: normalize_states_ runs in libiqlhip.so and needs a GPU buffer")
+        dev = self._rows.device
+        m = torch.as_tensor(np.ascontiguousarray(mean, dtype=np.float32).reshape(-1)).to(dev)
+        s = torch.as_tensor(np.ascontiguousarray(std, dtype=np.float32).reshape(-1)).to(dev)
+        if m.numel() != self._state_dim or s.numel() != self._state_dim:
+            raise ValueError("mean / std must have state_dim entries")
+        with torch.cuda.device(dev):
+            hb.check(hb.lib().iqlhip_rows_normalize(self._rows.data_ptr(), self._ld, self._state_dim, self._action_dim,
+                                                    0, self._size, m.data_ptr(), s.data_ptr(), self._stream()))
+
     def _index_bound(self) -> int:
         return self._size
 

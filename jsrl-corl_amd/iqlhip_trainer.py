@@ -408,6 +408,44 @@ class ImplicitQLearning:
         del keep
         return log
 
+    def online_step(self, replay_buffer, state, action, reward: float, next_state, done: bool,
+                    batch_size: int) -> Dict[str, float]:
+        """One iteration of the online loop's buffer + training work in ONE library call (reference sequence:
+        `replay_buffer.add_transition(...)`, `batch = replay_buffer.sample(batch_size)`, `trainer.train(batch)` —
+        algorithms/finetune/iql.py:741-773, jsrl_w_iql.py:512-548): the transition is stored at the ring pointer, the
+        batch indices are drawn by np.random.randint over the NEW size (same global-RNG draw as sample()), the rows
+        are gathered and the step runs; returns train()'s dict.  Equivalent to the three calls, bit for bit."""
+        self._prepare(batch_size)
+        buf = replay_buffer
+        if not getattr(buf, "_gpu", False) or buf._rows.device != self._dev:
+            raise ValueError("online_step needs a ReplayBuffer on the trainer's GPU")
+        S, A = self._S, self._A
+        row = getattr(self, "_on_row", None)
+        if row is None or row.shape[0] != buf._ld:
+            row = self._on_row = np.zeros(buf._ld, dtype=np.float32)
+        row[:S] = np.asarray(state, dtype=np.float32).reshape(-1)
+        row[S: S + A] = np.asarray(action, dtype=np.float32).reshape(-1)
+        row[S + A: 2 * S + A] = np.asarray(next_state, dtype=np.float32).reshape(-1)
+        row[2 * S + A] = np.float32(reward)
+        row[2 * S + A + 1] = np.float32(done)
+        pointer = buf._pointer
+        buf._pointer = (buf._pointer + 1) % buf._buffer_size
+        buf._size = min(buf._size + 1, buf._buffer_size)
+        idx = np.random.randint(0, buf._index_bound(), size=batch_size)
+        if idx.dtype != np.int64:
+            idx = idx.astype(np.int64)
+        self.total_it += 1
+        for g in self._adam_t:
+            self._adam_t[g] += 1
+        sc = hb.StepScalars()
+        self._fill_scalars(sc, self._adam_t, self._current_lrs(), dp.inv_batch(batch_size, self._dp_world))
+        out = (C.c_float * 3)()
+        hb.check(hb.lib().iqlhip_online_step(self._ctx, buf._rows.data_ptr(), buf._ld, buf._buffer_size, pointer,
+                                             row.ctypes.data, idx.ctypes.data, batch_size, C.byref(sc), out,
+                                             self._stream()))
+        self._advance_schedule(1)
+        return {"value_loss": float(out[0]), "q_loss": float(out[1]), "actor_loss": float(out[2])}
+
     def _schedule_state(self):
         sch = self.actor_lr_schedule
         lr = float(self.actor_optimizer.param_groups[0]["lr"])

@@ -244,6 +244,43 @@ def test_bench_launcher_fans_out_one_rank_per_gpu_without_touching_the_gpu():
     assert bad.returncode == 2 and "WORLD_SIZE=2" in bad.stderr
 
 
+def test_offline_flavour_surface_matches_reference_fixture():
+    """iql_offline.py (drop-in for algorithms/offline/iql.py) against fixture g15, generated from the reference's
+    offline module: the `is not None` dropout gate (state_dict keys for dropout None / 0.0 / 0.1), the unconditional
+    LR schedule in the checkpoint, TrainConfig's fields and defaults, the buffer's add_transition."""
+    import dataclasses
+    import iql_offline as off
+    z, meta = load_golden("g15_offline_surface")
+    for tag, d in (("none", None), ("zero", 0.0), ("p10", 0.1)):
+        assert list(off.MLP([5, 7, 7, 3], dropout=d).state_dict().keys()) == meta["mlp_keys"][tag]
+        assert list(off.GaussianPolicy(5, 3, 1.0, dropout=d).state_dict().keys()) == meta["policy_keys"][tag]["gauss"]
+        assert list(off.DeterministicPolicy(5, 3, 1.0, dropout=d).state_dict().keys()) == meta["policy_keys"][tag]["det"]
+    assert list(off.GaussianPolicy(5, 3, 1.0).state_dict().keys()) == meta["policy_default_dropout_keys"]
+    # the finetune flavour differs exactly at dropout = 0.0 (gate `> 0.0`, finetune/iql.py:332)
+    assert list(iql.MLP([5, 7, 7, 3], dropout=0.0).state_dict().keys()) == meta["mlp_keys"]["none"]
+    assert isinstance(off.GaussianPolicy(5, 3, 1.0), iql.GaussianPolicy)          # isinstance checks keep working
+    q, v, a = off.TwinQ(5, 3), off.ValueFunction(5), off.GaussianPolicy(5, 3, 1.0)
+    tr = off.ImplicitQLearning(1.0, a, torch.optim.Adam(a.parameters(), lr=3e-4), q, torch.optim.Adam(q.parameters(), lr=3e-4),
+                               v, torch.optim.Adam(v.parameters(), lr=3e-4), max_steps=10, device="cpu")
+    sd = tr.state_dict()
+    assert list(sd.keys()) == meta["state_dict_keys"]
+    assert sorted(sd["actor_lr_schedule"].keys()) == meta["schedule_state_keys"]
+    assert (getattr(tr, "partial_load_state_dict", None) is not None) == meta["has_partial_load"]
+    tr2 = off.ImplicitQLearning(1.0, a, torch.optim.Adam(a.parameters(), lr=3e-4), q, torch.optim.Adam(q.parameters(), lr=3e-4),
+                                v, torch.optim.Adam(v.parameters(), lr=3e-4), max_steps=10, device="cpu")
+    tr2.load_state_dict(sd)
+    cfg = off.TrainConfig()
+    want = meta["train_config"]
+    assert [f.name for f in dataclasses.fields(cfg)] == list(want.keys())
+    for k, val in want.items():
+        if k not in ("name", "checkpoints_path"):
+            assert getattr(cfg, k) == val, k
+    buf = off.ReplayBuffer(3, 2, 8, "cpu")
+    with pytest.raises(NotImplementedError):
+        buf.add_transition()
+    assert meta["add_transition"] == "NotImplementedError"
+
+
 def test_unsupported_configurations_fail_loudly():
     tr = _cpu_trainer()
     tr.v_optimizer.param_groups[0]["weight_decay"] = 0.1

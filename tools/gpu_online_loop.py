@@ -39,7 +39,7 @@ class ToyEnv:
         return self.s, (0.0 if goal else -1.0), done, {}
 
 
-def main(iters=3000, S=29, A=8, B=256, ring=10_000):
+def main(iters=3000, S=29, A=8, B=256, ring=10_000, fused=False):
     dev = "cuda"
     torch.manual_seed(0)
     np.random.seed(0)
@@ -66,12 +66,16 @@ def main(iters=3000, S=29, A=8, B=256, ring=10_000):
         c1 = time.perf_counter()
         ns, r, d, _ = env.step(a)
         c2 = time.perf_counter()
-        buf.add_transition(state, a, r, ns, d)
-        c3 = time.perf_counter()
-        batch = buf.sample(B)
-        batch = [b.to(dev) for b in batch]
-        c4 = time.perf_counter()
-        log = tr.train(batch)
+        if fused:      # add_transition + sample + train as ONE library call (ImplicitQLearning.online_step)
+            c3 = c4 = c2
+            log = tr.online_step(buf, state, a, r, ns, d, B)
+        else:
+            buf.add_transition(state, a, r, ns, d)
+            c3 = time.perf_counter()
+            batch = buf.sample(B)
+            batch = [b.to(dev) for b in batch]
+            c4 = time.perf_counter()
+            log = tr.train(batch)
         c5 = time.perf_counter()
         state = env.reset() if d else ns
         for k, v in zip(t, (c1 - c0, c2 - c1, c3 - c2, c4 - c3, c5 - c4)):
@@ -79,10 +83,11 @@ def main(iters=3000, S=29, A=8, B=256, ring=10_000):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert all(np.isfinite(v) for v in log.values())
-    print(f"online loop (S={S}, A={A}, B={B}, ring {ring}): {iters / dt:.0f} iterations/s, {dt / iters * 1e6:.1f} us each; "
+    print(f"online loop{' [fused online_step]' if fused else ''} (S={S}, A={A}, B={B}, ring {ring}): {iters / dt:.0f} iterations/s, {dt / iters * 1e6:.1f} us each; "
           + ", ".join(f"{k} {v / iters * 1e6:.1f} us" for k, v in t.items()))
     return iters / dt
 
 
 if __name__ == "__main__":
     main()
+    main(fused=True)

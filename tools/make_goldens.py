@@ -597,6 +597,40 @@ def bf16_largebatch_case(ref, name, outdir, stride=13):
     dropout_case(ref, name, 39, 28, True, 0.1, 1024, 82, stride, outdir)
 
 
+def offline_surface_case(ref_root, outdir):
+    """G15: the OFFLINE flavour's surface (algorithms/offline/iql.py, imported under another module name): state_dict
+    keys of MLP / policies for dropout None / 0.0 / 0.1 (gate `is not None`, :287), the always-present LR schedule
+    (:422, :513-537), TrainConfig's fields and defaults (:30-85), the buffer's sample bound and add_transition."""
+    import dataclasses
+    spec = importlib.util.spec_from_file_location("ref_offline_iql", os.path.join(ref_root, "algorithms", "offline", "iql.py"))
+    off = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(off)
+    desc = {"mlp_keys": {}, "policy_keys": {}}
+    for tag, d in (("none", None), ("zero", 0.0), ("p10", 0.1)):
+        desc["mlp_keys"][tag] = list(off.MLP([5, 7, 7, 3], dropout=d).state_dict().keys())
+        desc["policy_keys"][tag] = {"gauss": list(off.GaussianPolicy(5, 3, 1.0, dropout=d).state_dict().keys()),
+                                    "det": list(off.DeterministicPolicy(5, 3, 1.0, dropout=d).state_dict().keys())}
+    desc["policy_default_dropout_keys"] = list(off.GaussianPolicy(5, 3, 1.0).state_dict().keys())
+    q, v, a = off.TwinQ(5, 3), off.ValueFunction(5), off.GaussianPolicy(5, 3, 1.0)
+    tr = off.ImplicitQLearning(1.0, a, torch.optim.Adam(a.parameters(), lr=3e-4), q, torch.optim.Adam(q.parameters(), lr=3e-4),
+                               v, torch.optim.Adam(v.parameters(), lr=3e-4), max_steps=10, device="cpu")
+    sd = tr.state_dict()
+    desc["state_dict_keys"] = list(sd.keys())
+    desc["schedule_state_keys"] = sorted(sd["actor_lr_schedule"].keys())
+    desc["has_partial_load"] = hasattr(tr, "partial_load_state_dict")
+    cfg = off.TrainConfig()
+    desc["train_config"] = {f.name: (getattr(cfg, f.name) if f.name not in ("name", "checkpoints_path") else None)
+                            for f in dataclasses.fields(cfg)}
+    buf = off.ReplayBuffer(3, 2, 8, "cpu")
+    try:
+        buf.add_transition()
+        desc["add_transition"] = "ok"
+    except NotImplementedError:
+        desc["add_transition"] = "NotImplementedError"
+    np.savez(os.path.join(outdir, "g15_offline_surface.npz"), meta=np.array(json.dumps(desc)))
+    print("g15_offline_surface ok:", desc["mlp_keys"]["zero"])
+
+
 def round2_cases(ref, args):
     jsrl = import_reference_jsrl(args.ref)
     resume_case(ref, "g11_resume_S17A6_gauss", 17, 6, True, 110, 13, args.out)
@@ -604,6 +638,7 @@ def round2_cases(ref, args):
     jsrl_handoff_case(ref, jsrl, "g12_jsrl_handoff_S29A8", 29, 8, 120, 13, args.out)
     jsrl_hostlogic_case(jsrl, args.out)
     bf16_largebatch_case(ref, "g14_c5_B1024_dropout", args.out)
+    offline_surface_case(args.ref, args.out)
 
 
 def main():
