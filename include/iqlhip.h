@@ -153,10 +153,14 @@ int iqlhip_step(iqlhip_ctx* ctx, const iqlhip_batch* batch, const iqlhip_step_sc
  * 512-548: add_transition -> sample -> train) in one call: the new packed transition row_host[ld] is stored at ring
  * row `pointer` of rows_dev (capacity rows), the batch rows_dev[idx_host[0..n)] (indices as np.random.randint drew them,
  * AFTER the insert, iql.py:172) is gathered and one IQL step runs on it.  row_host / idx_host are ordinary host
- * memory (copied into pinned staging inside the call).  Synchronous: returns the three losses in out[3]. */
+ * memory (copied into pinned staging inside the call).  Synchronous: returns the three losses in out[3].
+ * act_state_host != NULL additionally evaluates the NEXT iteration's actor.act(state) (iql.py:371-379) with the
+ * just-updated policy before the call's one synchronisation: state_dim floats in, action_dim floats out
+ * (act_out_host); act_seed != 0 draws the training-mode noise on the device like iqlhip_actor_sample. */
 int iqlhip_online_step(iqlhip_ctx* ctx, float* rows_dev, int64_t ld, int64_t capacity, int64_t pointer,
                        const float* row_host, const int64_t* idx_host, int32_t n, const iqlhip_step_scalars* sc,
-                       float out[3], void* stream);
+                       float out[3], const float* act_state_host, float max_action, uint64_t act_seed,
+                       float* act_out_host, void* stream);
 
 /* Data-parallel split of the same step: forward+backward, then the
  * flat gradient (n_params floats + 4 tail words: 3 loss sums and a spare) is

@@ -96,6 +96,7 @@ struct iqlhip_ctx {
   float* on_row_pin = nullptr;        // iqlhip_online_step: pinned, host-mapped staging of the new transition [row_ld]
   long long* on_idx_pin = nullptr;    // ... and of the sampled indices [max_batch]
   float* on_loss_pin = nullptr;       // ... and the landing words of the step's three losses [4]
+  float* on_act_pin = nullptr;        // ... and of the follow-up act(): state in [IQLHIP_MAX_INPUT], action out [IQLHIP_MAX_ACTION]
   int act_cap = 0;
   unsigned long long act_calls = 0;   // Philox call counter of iqlhip_actor_sample
   int64_t row_ld = 0;
@@ -222,6 +223,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   HIPCHK(hipHostMalloc((void**)&c->on_row_pin, (size_t)c->row_ld * sizeof(float), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&c->on_idx_pin, (size_t)MB * sizeof(long long), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&c->on_loss_pin, 4 * sizeof(float), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&c->on_act_pin, (size_t)(IQLHIP_MAX_INPUT + IQLHIP_MAX_ACTION) * sizeof(float), hipHostMallocDefault));
   c->act_cap = std::max(MB, IQLHIP_ACT_ROWS);
   HIPCHK(dalloc(&c->xb_act, (size_t)c->act_cap * c->row_ld));
   HIPCHK(dalloc(&c->heads_act, (size_t)c->act_cap * A * NSPLIT));
@@ -340,6 +342,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   if (c->on_row_pin) (void)hipHostFree(c->on_row_pin);
   if (c->on_idx_pin) (void)hipHostFree(c->on_idx_pin);
   if (c->on_loss_pin) (void)hipHostFree(c->on_loss_pin);
+  if (c->on_act_pin) (void)hipHostFree(c->on_act_pin);
   delete c;
   return IQLHIP_OK;
 }
@@ -848,13 +851,19 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   return IQLHIP_OK;
 }
 
+static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
+                              int64_t ld_noise, uint64_t rng_seed, uint64_t rng_call, float max_action,
+                              float* actions_dev, int64_t ld_a, void* stream);
+
 // One iteration of the online loop's device work (algorithms/finetune/iql.py:741-773: add_transition -> sample ->
 // train) in ONE call and four launches: ring write + gather straight from pinned host words, forward, backward, update
 // with the losses landing in pinned host words; then one stream synchronisation.
 extern "C" int iqlhip_online_step(iqlhip_ctx* c, float* rows_dev, int64_t ld, int64_t capacity, int64_t pointer,
                                   const float* row_host, const int64_t* idx_host, int32_t n,
-                                  const iqlhip_step_scalars* sc, float out[3], void* stream) {
+                                  const iqlhip_step_scalars* sc, float out[3], const float* act_state_host,
+                                  float max_action, uint64_t act_seed, float* act_out_host, void* stream) {
   if (!c || !rows_dev || !row_host || !idx_host || !sc || !out) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (act_state_host && !act_out_host) return fail(IQLHIP_EINVAL, "act_state_host without act_out_host");
   if (!c->params) return fail(IQLHIP_ENOTBOUND, "iqlhip_bind has not been called");
   if (ld != c->row_ld) return fail(IQLHIP_EINVAL, "row stride must be iqlhip_row_stride(S,A)=%lld", (long long)c->row_ld);
   if (((uintptr_t)rows_dev) & 15) return fail(IQLHIP_EINVAL, "packed rows must be 16-byte aligned");
@@ -876,8 +885,20 @@ extern "C" int iqlhip_online_step(iqlhip_ctx* c, float* rows_dev, int64_t ld, in
   int rc = enqueue_step(c, p, u, c->xch_mode, (int)(c->xstep & 1ull), 0, /*from_hdr=*/false, st, nullptr);
   if (rc) return rc;
   if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += 1;
+  const int S = c->dims.state_dim, A = c->dims.action_dim;
+  if (act_state_host) {
+    // the NEXT iteration's actor.act(next_state) with the just-updated policy, in the same stream and under the
+    // same synchronisation: state and action travel through host-mapped pinned words
+    memcpy(c->on_act_pin, act_state_host, (size_t)S * sizeof(float));
+    float* a_out = c->on_act_pin + IQLHIP_MAX_INPUT;
+    rc = (act_seed != 0 && c->dims.policy == IQLHIP_POLICY_GAUSSIAN)
+             ? actor_forward_impl(c, c->on_act_pin, S, 1, nullptr, 0, act_seed, c->act_calls++, max_action, a_out, A, stream)
+             : actor_forward_impl(c, c->on_act_pin, S, 1, nullptr, 0, 0, 0, max_action, a_out, A, stream);
+    if (rc) return rc;
+  }
   HIPCHK(hipStreamSynchronize(st));        // (a synchronous call: the pinned staging words are free again on return)
   out[0] = c->on_loss_pin[0]; out[1] = c->on_loss_pin[1]; out[2] = c->on_loss_pin[2];
+  if (act_state_host) memcpy(act_out_host, c->on_act_pin + IQLHIP_MAX_INPUT, (size_t)A * sizeof(float));
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }
@@ -1329,9 +1350,6 @@ extern "C" int iqlhip_rows_sample_packed(const float* rows_dev, int64_t ld, cons
 
 // ---------------------------------------------------------------------------
 // Policy inference: pack states -> forward of the policy instance only -> tanh / noise / scale / clamp.
-static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
-                              int64_t ld_noise, uint64_t rng_seed, uint64_t rng_call, float max_action,
-                              float* actions_dev, int64_t ld_a, void* stream);
 
 extern "C" int iqlhip_actor_forward(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows,
                                     const float* noise_dev, int64_t ld_noise, float max_action, float* actions_dev,

@@ -77,7 +77,8 @@ SYMBOLS = [
     ("iqlhip_debug_write_masks", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("iqlhip_step", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(StepScalars), C.c_void_p]),
     ("iqlhip_online_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
-                                     C.c_int32, C.POINTER(StepScalars), C.POINTER(C.c_float), C.c_void_p]),
+                                     C.c_int32, C.POINTER(StepScalars), C.POINTER(C.c_float), C.c_void_p, C.c_float,
+                                     C.c_uint64, C.c_void_p, C.c_void_p]),
     ("iqlhip_forward_backward", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(StepScalars), C.c_void_p, C.c_void_p]),
     ("iqlhip_apply_update", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StepScalars), C.c_void_p]),
     ("iqlhip_grad_words", C.c_int64, [C.c_void_p]),

@@ -409,12 +409,15 @@ class ImplicitQLearning:
         return log
 
     def online_step(self, replay_buffer, state, action, reward: float, next_state, done: bool,
-                    batch_size: int) -> Dict[str, float]:
+                    batch_size: int, act_next: Optional[np.ndarray] = None):
         """One iteration of the online loop's buffer + training work in ONE library call (reference sequence:
         `replay_buffer.add_transition(...)`, `batch = replay_buffer.sample(batch_size)`, `trainer.train(batch)` —
         algorithms/finetune/iql.py:741-773, jsrl_w_iql.py:512-548): the transition is stored at the ring pointer, the
         batch indices are drawn by np.random.randint over the NEW size (same global-RNG draw as sample()), the rows
-        are gathered and the step runs; returns train()'s dict.  Equivalent to the three calls, bit for bit."""
+        are gathered and the step runs; returns train()'s dict.  Equivalent to the three calls, bit for bit.
+        `act_next` (a state, normally `next_state` unless the episode ended) additionally returns
+        `self.actor.act(act_next, device)` evaluated with the UPDATED policy — what the loop's next iteration would
+        compute first (iql.py:728) — under the same single synchronisation: returns (log, action)."""
         self._prepare(batch_size)
         buf = replay_buffer
         if not getattr(buf, "_gpu", False) or buf._rows.device != self._dev:
@@ -440,11 +443,22 @@ class ImplicitQLearning:
         sc = hb.StepScalars()
         self._fill_scalars(sc, self._adam_t, self._current_lrs(), dp.inv_batch(batch_size, self._dp_world))
         out = (C.c_float * 3)()
+        a_in = a_out = None
+        seed = 0
+        if act_next is not None:
+            from iqlhip_networks import dropout_p
+            if self.actor.training and dropout_p(self.actor) > 0.0:
+                raise NotImplementedError("act_next: the library's inference forward is eval-mode (no actor dropout)")
+            a_in = np.ascontiguousarray(np.asarray(act_next, dtype=np.float32).reshape(-1))
+            a_out = np.empty(A, dtype=np.float32)
+            seed = self._act_seed() if (self.actor.training and self._gaussian) else 0
         hb.check(hb.lib().iqlhip_online_step(self._ctx, buf._rows.data_ptr(), buf._ld, buf._buffer_size, pointer,
                                              row.ctypes.data, idx.ctypes.data, batch_size, C.byref(sc), out,
-                                             self._stream()))
+                                             None if a_in is None else a_in.ctypes.data, float(self.actor.max_action),
+                                             seed, None if a_out is None else a_out.ctypes.data, self._stream()))
         self._advance_schedule(1)
-        return {"value_loss": float(out[0]), "q_loss": float(out[1]), "actor_loss": float(out[2])}
+        log = {"value_loss": float(out[0]), "q_loss": float(out[1]), "actor_loss": float(out[2])}
+        return log if act_next is None else (log, a_out)
 
     def _schedule_state(self):
         sch = self.actor_lr_schedule

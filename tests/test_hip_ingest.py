@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 def test_device_mean_std_and_normalisation_against_numpy():
     """compute_mean_std / normalize_states (finetune/iql.py:77-84) on the device.  Stated tolerance: the float64-
     accumulated device reduction agrees with a float64 numpy evaluation to 1e-6 relative (it is the more exact of the
-    two) and with numpy's own float32 result — what the reference computes — to 2e-5 relative; the normalisation is
-    bit-identical to numpy's given the same mean / std."""
+    two) and with numpy's own float32 result — what the reference computes — to 1e-3 relative at this size: numpy reduces
+    axis 0 of a float32 array by adding the rows one after the other in float32, so ITS error grows with the row count
+    (observed here, 1 M rows with offsets up to 50: 1.8e-4 of |mean| + std, while the device result sits at < 1e-6 of
+    the float64 value).  The normalisation is bit-identical to numpy's given the same mean / std."""
     import iql
     S, A, N = 17, 6, 1_000_003
     rng = np.random.default_rng(5)
@@ -33,7 +35,7 @@ def test_device_mean_std_and_normalisation_against_numpy():
     assert mean.dtype == np.float32 and std.shape == (S,)
     assert np.max(np.abs(mean - m64) / (np.abs(m64) + s64)) <= 1e-6
     assert np.max(np.abs(std - s64) / s64) <= 1e-6
-    assert np.max(np.abs(mean - m32) / (np.abs(m32) + s32)) <= 2e-5 and np.max(np.abs(std - s32) / s32) <= 2e-5
+    assert np.max(np.abs(mean - m32) / (np.abs(m32) + s32)) <= 1e-3 and np.max(np.abs(std - s32) / s32) <= 1e-3
     again = buf.state_mean_std(eps)
     assert np.array_equal(again[0], mean) and np.array_equal(again[1], std)          # deterministic
     # in-place normalisation with numpy's own mean / std: bit-identical rows
@@ -120,4 +122,20 @@ def test_online_step_equals_add_sample_train():
         tr_b._fill_scalars(sc, {"v": 1, "q": 1, "pi": 1}, tr_b._current_lrs(), 1.0 / B)
         out = (C.c_float * 3)()
         hb.check(hb.lib().iqlhip_online_step(tr_b._ctx, buf_b._rows.data_ptr(), buf_b._ld, cap, 0, row.ctypes.data,
-                                             bad.ctypes.data, B, C.byref(sc), out, tr_b._stream()))
+                                             bad.ctypes.data, B, C.byref(sc), out, None, 1.0, 0, None, tr_b._stream()))
+    # act_next: the next iteration's act() under the same synchronisation == a separate actor.act() after the step
+    for mode in ("eval", "train"):
+        getattr(tr_a.actor, mode)()
+        getattr(tr_b.actor, mode)()
+        np.random.seed(9)
+        buf_a.add_transition(stream["observations"][0], stream["actions"][0], -1.0, stream["next_observations"][0], False)
+        la = tr_a.train(buf_a.sample(B))
+        aa = tr_a.actor.act(stream["next_observations"][0], "cuda")
+        np.random.seed(9)
+        lb, ab = tr_b.online_step(buf_b, stream["observations"][0], stream["actions"][0], -1.0,
+                                  stream["next_observations"][0], False, B, act_next=stream["next_observations"][0])
+        assert la == lb and ab.shape == (A,)
+        if mode == "eval":
+            assert np.array_equal(aa, ab)            # the mean action: same kernels, same weights
+        else:                                        # training mode: each trainer draws from its own Philox stream position
+            assert np.all(np.abs(ab) <= 1.0) and tr_b._ctx is not None

@@ -4,7 +4,9 @@ outputs of the reference captured by tools/make_goldens.py.  CPU only.
 Tolerances: the reference runs in fp32, and so does the oracle; two fp32
 evaluations of the same maths in different summation orders differ by ~1e-7
 relative on the losses and up to ~1e-5 relative-to-max on gradient tensors
-with heavy cancellation (observed: 1.1e-5 on one tensor), hence grad_rtol 3e-5.
+with heavy cancellation (observed: 1.1e-5 on one tensor), hence grad_rtol 3e-5 and — a first-step Adam moment being (1 - beta) * g — moment_rtol 5e-5 HERE (numpy's
+summation order vs aten's; observed 1.08e-5 on one bias).  The HIP kernels are held to the tighter 1e-5 / 1e-5 in
+tests/test_hip_parity.py (observed 2.6e-6 / 5.4e-6, profiles/r02_parity_margins.txt).
 """
 import numpy as np
 import pytest
@@ -23,7 +25,7 @@ def test_single_step_matches_reference(name):
     opt = O.new_opt_state(params)
     newp, newo, info = O.iql_step(params, opt, batch, hyper, meta["lrs"])
     check_step_against_golden(z, meta, info, newp, newo, grad_rtol=3e-5, param_atol=2e-6,
-                              loss_rtol=1e-5, target_atol=1e-7)
+                              loss_rtol=1e-5, target_atol=1e-7, moment_rtol=5e-5)
 
 
 @pytest.mark.parametrize("name", FREERUN_CASES)
@@ -138,7 +140,7 @@ def test_dropout_step_with_injected_masks_matches_reference(name):
     newp, newo, info = O.iql_step(params, O.new_opt_state(params), batch, hyper, meta["lrs"], actor_masks=masks)
     info2 = {k: v for k, v in info.items() if k not in ("next_v", "target_q", "adv")}
     check_step_against_golden(z, meta, info2, newp, newo, grad_rtol=3e-5, param_atol=2e-6, loss_rtol=1e-5,
-                              target_atol=1e-7)
+                              target_atol=1e-7, moment_rtol=5e-5)
     bits = synth.pack_keep_bits(k0)
     assert bits.shape == (meta["B"], 8) and ((bits[3, 1] >> 5) & 1) == int(k0[3, 37])
 
@@ -220,7 +222,8 @@ def test_jsrl_handoff_matches_reference():
     newp, newo, info = O.iql_step(learner, O.new_opt_state(learner), batch, hyper, meta["lrs"])
     assert_losses([info["value_loss"], info["q_loss"], info["actor_loss"]], z["losses"], 1e-5)
     check_step_against_golden(z, meta, {k: v for k, v in info.items() if k in ("value_loss", "q_loss", "actor_loss", "grads")},
-                              newp, newo, grad_rtol=3e-5, param_atol=2e-6, loss_rtol=1e-5, target_atol=1e-7)
+                              newp, newo, grad_rtol=3e-5, param_atol=2e-6, loss_rtol=1e-5, target_atol=1e-7,
+                              moment_rtol=5e-5)
     assert meta["total_it_after_step"] == meta["offline_iterations"] + 1
 
 
@@ -234,4 +237,4 @@ def test_config5_share_with_dropout_matches_reference():
     newp, newo, info = O.iql_step(params, O.new_opt_state(params), batch, hyper, meta["lrs"], actor_masks=masks)
     info2 = {k: v for k, v in info.items() if k not in ("next_v", "target_q", "adv")}
     check_step_against_golden(z, meta, info2, newp, newo, grad_rtol=3e-5, param_atol=2e-6, loss_rtol=1e-5,
-                              target_atol=1e-7)
+                              target_atol=1e-7, moment_rtol=5e-5)

@@ -56,19 +56,23 @@ def main(iters=3000, S=29, A=8, B=256, ring=10_000, fused=False):
         buf.add_transition(state, a, r, ns, d)
         state = env.reset() if d else ns
     t = {"act": 0.0, "env": 0.0, "add": 0.0, "sample": 0.0, "train": 0.0}
+    next_a = None
     for it in range(iters + 200):
         if it == 200:
             torch.cuda.synchronize()
             t = {k: 0.0 for k in t}
             t0 = time.perf_counter()
         c0 = time.perf_counter()
-        a = actor.act(state, dev)
+        a = next_a if (fused and next_a is not None) else actor.act(state, dev)
         c1 = time.perf_counter()
         ns, r, d, _ = env.step(a)
         c2 = time.perf_counter()
         if fused:      # add_transition + sample + train as ONE library call (ImplicitQLearning.online_step)
             c3 = c4 = c2
-            log = tr.online_step(buf, state, a, r, ns, d, B)
+            if d:
+                log, next_a = tr.online_step(buf, state, a, r, ns, d, B), None
+            else:          # the next iteration's act(ns) rides in the same call (same updated policy, one sync)
+                log, next_a = tr.online_step(buf, state, a, r, ns, d, B, act_next=ns)
         else:
             buf.add_transition(state, a, r, ns, d)
             c3 = time.perf_counter()
