@@ -287,9 +287,11 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
   HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
   HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
-  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
   HIPCHK(hipFuncSetAttribute((const void*)iql_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
-  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
   return IQLHIP_OK;
 }
 
@@ -553,8 +555,14 @@ static void launch_bwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st)
   const int n_chunk = (p.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
   const int per_net = 32 * n_chunk + 4 * n_rt;
   const dim3 grid(8 * ((per_net + 1) / 2));
-  if (c->precision == 1) hipLaunchKernelGGL(iql_bwd_kernel<true>, grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
-  else hipLaunchKernelGGL(iql_bwd_kernel<false>, grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+  const bool full = (p.rows % CHUNK_ROWS) == 0;      // every tile of every block lies inside the batch: no clamps
+  if (c->precision == 1) {
+    if (full) hipLaunchKernelGGL((iql_bwd_kernel<true, true>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+    else hipLaunchKernelGGL((iql_bwd_kernel<true, false>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+  } else {
+    if (full) hipLaunchKernelGGL((iql_bwd_kernel<false, true>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+    else hipLaunchKernelGGL((iql_bwd_kernel<false, false>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+  }
 }
 static unsigned drop_thresh(float p) {
   const double t = (double)p * 4294967296.0;

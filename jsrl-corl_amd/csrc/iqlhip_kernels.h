@@ -172,7 +172,7 @@ __device__ __forceinline__ void xr_issue(f32x4 (&xr)[XR_MAX_F4], const float* xb
 #pragma unroll
   for (int q = Q0; q < Q1; ++q) {
     const int f = min(first_f4 + min((int)threadIdx.x + 256 * q, n_x - 1), x_last);
-    xr[q] = *(const f32x4*)(xb + 4 * f);
+    xr[q] = *(const f32x4*)(xb + 4u * (unsigned)f);
   }
 }
 __device__ __forceinline__ void xr_load(f32x4 (&xr)[XR_MAX_F4], const float* xb, int first_f4, int n_x, int x_last) {
@@ -282,13 +282,13 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int e = min(tid + 256 * q, D * 16 - 1);
-    w2pre[q] = *(const f32x4*)(np.w2 + (e >> 4) * HID + ns * 64 + 4 * (e & 15));
+    w2pre[q] = *(const f32x4*)(np.w2 + (unsigned)((e >> 4) * HID + ns * 64 + 4 * (e & 15)));
   }
   const float b2v = np.b2[min(tid, D - 1)];
   f32x4 bias0[4];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) bias0[ct] = *(const f32x4*)(np.b0 + wave * 64 + ct * 16 + 4 * g);
-  const f32x4 bias1 = *(const f32x4*)(np.b1 + ns * 64 + wave * 16 + 4 * g);
+  for (int ct = 0; ct < 4; ++ct) bias0[ct] = *(const f32x4*)(np.b0 + (unsigned)(wave * 64 + ct * 16 + 4 * g));
+  const f32x4 bias1 = *(const f32x4*)(np.b1 + (unsigned)(ns * 64 + wave * 16 + 4 * g));
   // (b2) dropout keep-bits of this row tile (policy instance only): thread -> (row tid >> 3, word tid & 7)
   const bool drop = (inst == 6) && (p.drop_bits != nullptr);
   unsigned mk0 = 0xFFFFFFFFu, mk1 = 0xFFFFFFFFu;
@@ -309,10 +309,10 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       lds_dma16(np.w0 + 4 * min(tid + 256 * j, n_w0v - 1), W0s + 4 * (256 * j + 64 * wave));
   } else if (w0_lds) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w0v[j] = *(const f32x4*)(np.w0 + 4 * min(tid + 256 * j, n_w0v - 1));
+    for (int j = 0; j < 8; ++j) w0v[j] = *(const f32x4*)(np.w0 + 4u * (unsigned)min(tid + 256 * j, n_w0v - 1));
     if (k0 > 32) {
 #pragma unroll
-      for (int j = 8; j < 16; ++j) w0v[j] = *(const f32x4*)(np.w0 + 4 * min(tid + 256 * j, n_w0v - 1));
+      for (int j = 8; j < 16; ++j) w0v[j] = *(const f32x4*)(np.w0 + 4u * (unsigned)min(tid + 256 * j, n_w0v - 1));
     }
   }
   // (d) this wave's W1 rows (16 output units x 256 k) as MFMA fragments: 64 KiB per block
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   f32x4 bw[16];
   if (!w0_dma) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + n1 * HID + 16 * ks + 4 * g);
+    for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + (unsigned)(n1 * HID + 16 * ks + 4 * g));
   }
 
   xr_store(xr, Xr, n_x);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   __syncthreads();
   if (w0_dma) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + n1 * HID + 16 * ks + 4 * g);
+    for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + (unsigned)(n1 * HID + 16 * ks + 4 * g));
   }
   STAMP(p, 1);
 
@@ -597,13 +597,18 @@ struct RowIn {
 
 // The scalar per-row loss inputs of one row (issue only).  The policy's per-(row, dim) inputs are loaded by the
 // callers as coalesced (row, dim) work items.
+// (offsets are formed as 32-bit UNSIGNED values on uniform base pointers: the load then takes the SGPR-base +
+//  VGPR-offset form and needs no 64-bit address arithmetic on the vector ALU — with signed indices every load of
+//  the backward's issue phase cost a sign extension and a 64-bit multiply-add, ~300 extra instructions per block)
 __device__ __forceinline__ void row_issue(const StepParams& p, int row, RowIn& in) {
-  const f32x4* h = (const f32x4*)(p.sc.heads + row * HEAD_LD);
+  const float* hb = p.sc.heads;
+  const unsigned o = (unsigned)row * (unsigned)HEAD_LD;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) in.h[i] = h[i];
-  const float* xr = p.xb + row * p.ld + 2 * p.S + p.A;
-  in.r = xr[0];
-  in.d = xr[1];
+  for (int i = 0; i < 6; ++i) in.h[i] = *(const f32x4*)(hb + (o + 4u * i));
+  const float* xb = p.xb;
+  const unsigned ox = (unsigned)row * (unsigned)p.ld + (unsigned)(2 * p.S + p.A);
+  in.r = xb[ox];
+  in.d = xb[ox + 1u];
 }
 
 __device__ __forceinline__ float sum4(const f32x4 v) { return ((v[0] + v[1]) + v[2]) + v[3]; }
@@ -696,7 +701,34 @@ __device__ __forceinline__ void dh1_mfma(f32x4 (&pre)[4][2], const float* dYs, c
   }
 }
 
-template <bool BF16>
+// Policy loss terms of 8 (row, dim) items — one action dim, eight rows — as straight-line code: both policy kinds are
+// evaluated and selected on the (uniform) kind, dims beyond A on `live`; no branch, no memory access.
+//   gaussian: -log N(a; mu, sigma) = q/2 + log_sigma + log(2 pi)/2 with q = (a - mu)^2 / sigma^2   (iql.py:527)
+//   deterministic: (mu - a)^2                                                                     (iql.py:531)
+__device__ __forceinline__ void pi_items8(const f32x4 (&hv)[8], const float (&acv)[8], const float (&wv)[8], bool live,
+                                          bool gauss, float ivar, float ls, float invB, float (&dyv)[8], float (&dlv)[8],
+                                          float& lossA) {
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const float w = wv[cc];
+    const float mu = tanh_via_exp(sum4(hv[cc]));
+    const float diff = acv[cc] - mu;
+    const float q = diff * diff * ivar;
+    const float l_g = w * (0.5f * q + ls + 0.918938533204672742f);
+    const float l_d = w * (diff * diff);
+    const float dmu_g = (-(w * diff) * ivar) * invB;
+    const float dmu_d = (-2.f * w * diff) * invB;
+    const float dmu = gauss ? dmu_g : dmu_d;
+    lossA += live ? (gauss ? l_g : l_d) : 0.f;
+    dyv[cc] = live ? dmu * (1.f - mu * mu) : 0.f;
+    dlv[cc] = (live && gauss) ? w * (1.f - q) : 0.f;
+  }
+}
+
+// FULL: every row of every block's tile is a row of the batch (B % 256 == 0; the host selects the instantiation):
+// no row index is clamped, so consecutive loads differ by compile-time constants.
+#define BROW(r) (FULL ? (r) : min((r), B - 1))
+template <bool BF16, bool FULL>
 __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk, int n_rt) {
   RT_ENTRY();
   const int bid = blockIdx.x;
@@ -767,29 +799,32 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     RowIn in;
     const float lsr = pi_ls_issue(p);
     const bool is_pi = (net == IQLHIP_NET_PI);
-    row_issue(p, min(prow, B - 1), in);     // scalar partials, r, d (the policy needs h[1..3] for w)
+    row_issue(p, BROW(prow), in);           // scalar partials, r, d (the policy needs h[1..3] for w)
     // Policy: its per-(row, dim) inputs are loaded as (row, dim) work items — thread (r8 = tid >> 3, sub = tid & 7)
     // takes rows r8 + 32c, c = 0..7, and action dim sub (+ 8e) — so that one load instruction touches 6-8 cache
     // lines.  With thread = row every such load touched 48-64 lines; the 16 of them held the load queue for 8.5 k
     // cycles and made the policy's (a) blocks (10-13 us) the long pole of the whole kernel (others: 6-9 us).
     const int r8 = tid >> 3, sub = tid & 7;
     const f32x4* hpb = (const f32x4*)(p.sc.heads + MB * HEAD_LD);
+    const float* hpf = p.sc.heads + MB * HEAD_LD;
+    const float* xbp = p.xb;
     f32x4 php[8];
     float pac[8];
     if (is_pi) {
-      const int dd0 = min(sub, p.A - 1);
+      const unsigned dd0 = (unsigned)min(sub, p.A - 1);
+      const unsigned uA = (unsigned)p.A, uld = (unsigned)p.ld, uS = (unsigned)p.S;
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
-        const int rowc = min(cbase + r8 + 32 * cc, B - 1);
-        php[cc] = hpb[rowc * p.A + dd0];
-        pac[cc] = p.xb[rowc * p.ld + p.S + dd0];
+        const unsigned rowc = (unsigned)BROW(cbase + r8 + 32 * cc);
+        php[cc] = *(const f32x4*)(hpf + 4u * (rowc * uA + dd0));
+        pac[cc] = xbp[rowc * uld + uS + dd0];
       }
     }
     float w2pre[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ec = min(tid + 256 * q, D * 32 - 1);      // clamped: unconditional load
-      w2pre[q] = w2[(ec >> 5) * HID + j0 + (ec & 31)];
+      w2pre[q] = w2[(unsigned)((ec >> 5) * HID + j0 + (ec & 31))];
     }
     // wave w reduces its 64 rows, 4 per MFMA: instruction ks of lane group g takes row AROW(ks) = 64w + 16(ks>>2) +
     // 4g + (ks&3) — the row a lane's accumulator register (ks&3) of the 16-row tile (ks>>2) holds when dH1 itself
@@ -800,9 +835,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     f32x4 bb[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const int row = min(cbase + AROW(ks), B - 1);
-      hh[ks] = *(const f32x2*)(H1g + row * HID + j0 + 2 * l15);
-      bb[ks] = *(const f32x4*)(H0g + row * HID + i0 + 4 * l15);
+      const unsigned row = (unsigned)BROW(cbase + AROW(ks));
+      hh[ks] = *(const f32x2*)(H1g + (row * (unsigned)HID + (unsigned)(j0 + 2 * l15)));
+      bb[ks] = *(const f32x4*)(H0g + (row * (unsigned)HID + (unsigned)(i0 + 4 * l15)));
     }
     STAMP(p, 10);
     // ---- dY for the 256 rows of the chunk (thread = row)
@@ -827,63 +862,51 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           const float u = tq - sum4(in.h[1]);
           wrow = fminf(expf(p.hy.beta * u), p.hy.exp_adv_max);
         }
+        STAMP(p, 5);
         wS[tid] = wrow;
         __syncthreads();                       // (net is block-uniform)
-        // phase 2 (thread = (row, dim)): mean, log-prob term, dL/dpre and dL/dlog_std of every (row, dim)
+        STAMP(p, 6);
+        // phase 2 (thread = (row, dim)): mean, log-prob term, dL/dpre and dL/dlog_std of every (row, dim) — eight
+        // rows of one dim per thread and group of 8 dims, as straight-line select code (pi_items8): written with
+        // per-item branches this phase was ~110 LDS / branch round trips (3.3 k cycles, the policy blocks' long pole)
         const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
         const bool want_dls = designated && gauss;
         const int A = p.A;
         const float invB = p.inv_batch;
+        float wv[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) wv[cc] = wS[r8 + 32 * cc];
         for (int e = 0; 8 * e < Dp; ++e) {
           const int dd = sub + 8 * e;
-          if (8 * e >= A) {                    // padding dims up to Dp (MFMA operands): zeros, no loads
+          float dyv[8], dlv[8];
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-              dYs[(r8 + 32 * cc) * DYA + dd] = 0.f;
-              if (want_dls) dLs[(r8 + 32 * cc) * DYA + dd] = 0.f;
-            }
-            continue;
-          }
-          const int ddc = min(dd, A - 1);
-          const float ivar = __shfl(pc.ivar, ddc);       // lane ddc holds dim ddc's constants; the whole wave is here
-          const float ls = __shfl(pc.ls, ddc);
-          f32x4 hv[8];
-          float acv[8];
-          if (e == 0) {
+          for (int cc = 0; cc < 8; ++cc) { dyv[cc] = 0.f; dlv[cc] = 0.f; }
+          if (8 * e < A) {                     // (block-uniform; groups beyond A are padding up to Dp: zeros, no loads)
+            const int ddc = min(dd, A - 1);
+            const float ivar = __shfl(pc.ivar, ddc);     // lane ddc holds dim ddc's constants; the whole wave is here
+            const float ls = __shfl(pc.ls, ddc);
+            if (e == 0) {
+              pi_items8(php, pac, wv, dd < A, gauss, ivar, ls, invB, dyv, dlv, lossA);
+            } else {                           // action dims >= 8 (wide action spaces): loaded here, 8 at a time
+              f32x4 hv[8];
+              float acv[8];
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) { hv[cc] = php[cc]; acv[cc] = pac[cc]; }
-          } else {                             // action dims >= 8 (wide action spaces): loaded here, 8 at a time
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-              const int rowc = min(cbase + r8 + 32 * cc, B - 1);
-              hv[cc] = hpb[rowc * A + ddc];
-              acv[cc] = p.xb[rowc * p.ld + p.S + ddc];
-            }
-          }
-#pragma unroll
-          for (int cc = 0; cc < 8; ++cc) {
-            const int rl = r8 + 32 * cc;
-            const float w = wS[rl];
-            float dy = 0.f, dl = 0.f;
-            if (dd < A) {
-              const float mu = tanh_via_exp(sum4(hv[cc]));
-              const float diff = acv[cc] - mu;
-              float dmu;
-              if (gauss) {
-                const float q = diff * diff * ivar;
-                lossA += w * (0.5f * q + ls + 0.918938533204672742f);  // w * -log N(a; mu, sigma), per dim
-                dmu = (-(w * diff) * ivar) * invB;
-                dl = w * (1.f - q);
-              } else {
-                lossA += w * (diff * diff);
-                dmu = (-2.f * w * diff) * invB;
+              for (int cc = 0; cc < 8; ++cc) {
+                const unsigned rowc = (unsigned)BROW(cbase + r8 + 32 * cc);
+                hv[cc] = *(const f32x4*)(hpf + 4u * (rowc * (unsigned)A + (unsigned)ddc));
+                acv[cc] = xbp[rowc * (unsigned)p.ld + (unsigned)(p.S + ddc)];
               }
-              dy = dmu * (1.f - mu * mu);
+              pi_items8(hv, acv, wv, dd < A, gauss, ivar, ls, invB, dyv, dlv, lossA);
             }
-            dYs[rl * DYA + dd] = dy;
-            if (want_dls) dLs[rl * DYA + dd] = dl;
+          }
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) dYs[(r8 + 32 * cc) * DYA + dd] = dyv[cc];
+          if (want_dls) {
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) dLs[(r8 + 32 * cc) * DYA + dd] = dlv[cc];
           }
         }
+        STAMP(p, 7);
       }
       STAMP(p, 11);
       if (loss_block) {
@@ -1140,7 +1163,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 
     // ---- issue every global load of the block, first-needed first (vmcnt retires in issue order)
     RowIn in;
-    const int prow = min(row0 + (tid & 31), B - 1);
+    const int prow = BROW(row0 + (tid & 31));
     const float lsr = pi_ls_issue(p);
     // the scalar nets' per-row loss inputs are consumed by the first 32 threads only: wave 0 alone loads them
     // (these loads head the in-order queue — issued by all four waves they delayed every load behind them);
@@ -1152,14 +1175,15 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // policy: the loss arithmetic of the 32 rows is spread over all 256 threads — thread (row tid>>3,
     // dims (tid&7) + 8c) — instead of 32 threads walking all dims while 224 wait at the barrier
     const int prl = tid >> 3, psub = tid & 7;
-    const int prow8 = min(row0 + prl, B - 1);
+    const int prow8 = BROW(row0 + prl);
     f32x4 ph[3], php[4];
     float pac[4];
     if (net == IQLHIP_NET_PI) {
-      const f32x4* hs = (const f32x4*)(p.sc.heads + prow8 * HEAD_LD);
-      ph[0] = hs[1]; ph[1] = hs[2]; ph[2] = hs[3];
-      const float* arow = p.xb + prow8 * p.ld + p.S;
-      const f32x4* hp = (const f32x4*)(p.sc.heads + MB * HEAD_LD + prow8 * p.A * NSPLIT);
+      const float* hsb = p.sc.heads;
+      const unsigned oh = (unsigned)prow8 * (unsigned)HEAD_LD;
+      ph[0] = *(const f32x4*)(hsb + (oh + 4u)); ph[1] = *(const f32x4*)(hsb + (oh + 8u)); ph[2] = *(const f32x4*)(hsb + (oh + 12u));
+      const float* arow = p.xb + (unsigned)(prow8 * p.ld + p.S);
+      const f32x4* hp = (const f32x4*)(p.sc.heads + MB * HEAD_LD + (unsigned)(prow8 * p.A * NSPLIT));
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         php[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1185,21 +1209,21 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int f = tid + 256 * q;
-      const int row = min(row0 + (f >> 6), B - 1);   // rows >= B: dY = 0 -> dH1 = 0
-      h1v[q] = *(const f32x4*)(H1g + row * HID + 4 * (f & 63));
+      const unsigned row = (unsigned)BROW(row0 + (f >> 6));   // rows >= B: dY = 0 -> dH1 = 0
+      h1v[q] = *(const f32x4*)(H1g + (row * (unsigned)HID + (unsigned)(4 * (f & 63))));
     }
     // W1 fragments: k = j in [64*wave, +64), n = i0 + 4*l15 + t
     f32x4 bw[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-      bw[ks] = *(const f32x4*)(w1 + (64 * wave + 4 * ks + g) * HID + i0 + 4 * l15);
+      bw[ks] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * ks + g) * HID + i0 + 4 * l15));
     // H0 mask slice [32][64] as float4 f = tid + 256q: row f>>4, cols i0 + 4*(f&15)
     f32x4 h0v[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int f = tid + 256 * q;
-      const int row = min(row0 + (f >> 4), B - 1);
-      h0v[q] = *(const f32x4*)(H0g + row * HID + i0 + 4 * (f & 15));
+      const unsigned row = (unsigned)BROW(row0 + (f >> 4));
+      h0v[q] = *(const f32x4*)(H0g + (row * (unsigned)HID + (unsigned)(i0 + 4 * (f & 15))));
     }
     const int n_x = RT_ROWS * ld / 4;
     const int x_last = B * ld / 4 - 1;

@@ -101,7 +101,7 @@ ids = np.arange(nb)
 local = (ids >> 3) * 2 + ((ids & 7) >> 2)
 a_blocks = bw[local < 32 * n_chunk]
 b_blocks = bw[(local >= 32 * n_chunk) & (local < per_net)]
-LAB_A = [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
+LAB_A = [(10, "issue loads"), (5, "pi: row loads + w"), (6, "pi: wS barrier"), (7, "pi: (row,dim) math"), (11, "wait heads + dY (rest)"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
          (4, "reduce + store (+extras)")]
 LAB_B = [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"), (8, "reduce+mask"), (12, "dW0: LDS reads + MFMA"), (13, "dW0: stage T + barrier"), (9, "dW0: copy out")]
 if os.environ.get("PER_NET"):
