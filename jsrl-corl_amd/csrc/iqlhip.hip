@@ -132,7 +132,9 @@ struct iqlhip_ctx {
   void* nccl_comm = nullptr;
   // P2P: one exchange block per rank = [flags: IQLHIP_MAX_WORLD x 16 u64][flat 0][flat 1], exported through hipIpc
   char* xblk = nullptr;
-  size_t xblk_bytes = 0, xflat_off[2] = {0, 0};
+  size_t xblk_bytes = 0, xflat_off[2] = {0, 0};   // per parity buffer: [flat n_params+4 | slab_b (8 row tiles) | loss_parts]
+  size_t xslabb_off[2] = {0, 0}, xloss_off[2] = {0, 0};
+  long long xslab_b_off[4] = {0, 0, 0, 0};        // per-net offsets inside an exchange block's slab_b region (8 row tiles)
   char* peer_blk[IQLHIP_MAX_WORLD] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool p2p_attached = false;
   unsigned long long* xstatus = nullptr;   // device: [0] first timed-out step, [1] spare
@@ -270,6 +272,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   int w0_lds_k = 0;
   if (kq <= W0_DMA_MAX_K && fits(kq)) w0_lds_k = kq;
   else if (ks_ <= W0_DMA_MAX_K && fits(ks_)) w0_lds_k = ks_;
+  if (const char* ov = getenv("IQLHIP_W0_LDS_K")) w0_lds_k = std::min(w0_lds_k, atoi(ov));   // diagnostic (tools/): force a narrower staging
   c->w0_lds_k = w0_lds_k;
   c->lds_fwd = fwd_fixed + (size_t)HID * w0_lds_k * sizeof(float) + (w0_lds_k > W0_LDS_MAX_K ? 4096 : 0);
   // One block per CU while the grid fits the chip (co-resident blocks share a CU's L1 and fill rate and only slow
@@ -527,7 +530,8 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.d_bits = nullptr; u.d_n_words = 2 * c->dims.max_batch * 8; u.d_thresh = 0; u.d_hdr = c->hdr; u.d_k = 0;
   u.ring_hdr = nullptr;
   u.n_peer = 0;
-  for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) u.peer_flat[r] = nullptr;
+  u.peer_direct = 0;
+  for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) { u.peer_flat[r] = nullptr; u.peer_slab_b[r] = nullptr; u.peer_loss[r] = nullptr; }
   return u;
 }
 
@@ -663,9 +667,20 @@ extern "C" int iqlhip_p2p_export(iqlhip_ctx* c, void* handle_out, int rank, int 
   if (!c->xblk) {
     const size_t flags_b = 4096;                                     // IQLHIP_MAX_WORLD x 128-B flag lines, padded
     const size_t flat_b = (size_t)up((c->L.n_params + 4) * (int64_t)sizeof(float), 4096);
-    c->xflat_off[0] = flags_b;
-    c->xflat_off[1] = flags_b + flat_b;
-    c->xblk_bytes = flags_b + 2 * flat_b;
+    size_t sb = 0;                                                   // w0 / b0 partial slabs of <= 8 row tiles (<= 256 rows)
+    for (int n = 0; n < 4; ++n) {
+      c->xslab_b_off[n] = (long long)sb;
+      sb += (size_t)8 * ((size_t)HID * c->L.net[n].k_in + HID);
+    }
+    const size_t slabb_b = (size_t)up((int64_t)(sb * sizeof(float)), 4096);
+    const size_t loss_b = 4096;
+    const size_t buf_b = flat_b + slabb_b + loss_b;
+    for (int k = 0; k < 2; ++k) {
+      c->xflat_off[k] = flags_b + (size_t)k * buf_b;
+      c->xslabb_off[k] = c->xflat_off[k] + flat_b;
+      c->xloss_off[k] = c->xslabb_off[k] + slabb_b;
+    }
+    c->xblk_bytes = flags_b + 2 * buf_b;
     HIPCHK(hipMalloc((void**)&c->xblk, c->xblk_bytes));
     HIPCHK(hipMemset(c->xblk, 0, c->xblk_bytes));
     HIPCHK(hipDeviceSynchronize());
@@ -767,8 +782,21 @@ static XchParams make_xch(const iqlhip_ctx* c, bool from_hdr) {
 // One step's launches after the batch has been staged: forward, backward and — by exchange mode — the update, or
 // flatten + all-reduce + update, or flatten + flag handshake + the update that reads every rank's buffer.
 // `k` = position inside the chunk (selects the P2P buffer together with `parity`, and the flag value hdr[XSTEP]+k+1).
-static int enqueue_step(iqlhip_ctx* c, const StepParams& p, UpdParams u, int mode, int parity, int k, bool from_hdr,
+static int enqueue_step(iqlhip_ctx* c, const StepParams& p_in, UpdParams u, int mode, int parity, int k, bool from_hdr,
                         hipStream_t st, hipEvent_t* ev) {
+  StepParams p = p_in;
+  const int buf = (parity + k) & 1;
+  // P2P with batches of <= 256 rows: no flatten kernel.  The backward writes its chunk slab (= the w1 / b1 / w2 / b2 /
+  // log_std gradients themselves), its <= 8 row-tile slabs of w0 / b0 partials and its loss sums straight into this
+  // rank's exchange block; they are complete and written back at the kernel boundary in front of the flag kernel, and
+  // every rank's update kernel reads all ranks' blocks.
+  const bool direct = (mode == IQLHIP_XCH_P2P) && (p.rows <= CHUNK_ROWS);
+  if (direct) {
+    p.sc.slab_a = (float*)(c->xblk + c->xflat_off[buf]);
+    p.sc.slab_b = (float*)(c->xblk + c->xslabb_off[buf]);
+    for (int n = 0; n < 4; ++n) p.sc.slab_b_off[n] = c->xslab_b_off[n];
+    p.sc.loss_parts = (float*)(c->xblk + c->xloss_off[buf]);
+  }
   launch_fwd(c, p, st);
   if (ev) HIPCHK(hipEventRecord(ev[1], st));
   launch_bwd(c, p, st);
@@ -778,12 +806,17 @@ static int enqueue_step(iqlhip_ctx* c, const StepParams& p, UpdParams u, int mod
     NCCLCHK(g_rccl.AllReduce(c->xflat, c->xflat, (size_t)c->L.n_params + 4, RCCL_FLOAT32, RCCL_SUM, c->nccl_comm, st));
     u.flat_grads = c->xflat;
   } else if (mode == IQLHIP_XCH_P2P) {
-    const int buf = (parity + k) & 1;
-    launch_flatten(c, u, (float*)(c->xblk + c->xflat_off[buf]), true, st);
+    if (!direct) launch_flatten(c, u, (float*)(c->xblk + c->xflat_off[buf]), true, st);
     if (c->world > 1) hipLaunchKernelGGL(iql_xch_signal_wait_kernel, dim3(1), dim3(64), 0, st, make_xch(c, from_hdr), k);
-    for (int r = 0; r < IQLHIP_MAX_WORLD; ++r)
-      u.peer_flat[r] = (const float*)(c->peer_blk[std::min(r, c->world - 1)] + c->xflat_off[buf]);
+    for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) {
+      const char* blk = c->peer_blk[std::min(r, c->world - 1)];
+      u.peer_flat[r] = (const float*)(blk + c->xflat_off[buf]);
+      u.peer_slab_b[r] = (const float*)(blk + c->xslabb_off[buf]);
+      u.peer_loss[r] = (const float*)(blk + c->xloss_off[buf]);
+    }
     u.n_peer = c->world;
+    u.peer_direct = direct ? 1 : 0;
+    if (direct) for (int n = 0; n < 4; ++n) u.slab_b_off[n] = c->xslab_b_off[n];
   }
   launch_upd(c, u, st);
   if (ev) HIPCHK(hipEventRecord(ev[3], st));

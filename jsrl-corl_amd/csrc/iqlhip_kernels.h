@@ -1479,6 +1479,13 @@ struct UpdParams {
   // system-scope loads).  Every rank forms the same sum in the same order: replicas stay bitwise equal.
   const float* peer_flat[IQLHIP_MAX_WORLD];
   int n_peer;
+  // peer_direct: no flatten kernel ran — peer_flat[r] IS rank r's chunk slab (the backward wrote w1 / b1 / w2 / b2 /
+  // log_std gradients straight into the exchange block; batches of <= 256 rows have ONE chunk slab, i.e. the gradient
+  // itself), the w0 / b0 gradients are still per-row-tile partial slabs in peer_slab_b[r] (summed here, slab order
+  // then rank order) and the loss sums are in peer_loss[r] ([4][64] like DevScratch::loss_parts)
+  int peer_direct;
+  const float* peer_slab_b[IQLHIP_MAX_WORLD];
+  const float* peer_loss[IQLHIP_MAX_WORLD];
   float* loss_parts;
   float* losses;            // [4]
   float* losses_mirror;     // nullable: second copy of the three losses (host-mapped pinned words: iqlhip_online_step)
@@ -1732,14 +1739,34 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     if (PEER) {
       // all ranks' contributions requested together (one fabric round trip), summed in rank order
       static_assert(IQLHIP_MAX_WORLD == 8, "load16_sys_x8");
-      f32x4 pv[8];
-      const float* pp[8];
+      const iqlhip_net_layout& nl = u.L.net[net];
+      if (u.peer_direct && e >= nl.w0 && e < nl.b0 + HID) {
+        // w0 / b0: every rank's <= 8 row-tile partial slabs, summed per rank in slab order (exactly slab_grad's sum,
+        // i.e. what that rank's flatten kernel would have written), then over the ranks in rank order
+        const long long stride = (long long)HID * nl.k_in + HID;
+        const long long off = u.slab_b_off[net] + (e - nl.w0);
+        gr = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < u.n_peer; ++r) {
+          f32x4 pv[8];
+          const float* pp[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) pp[r] = u.peer_flat[min(r, u.n_peer - 1)] + e;
-      load16_sys_x8(pv, pp);
-      gr = pv[0];
+          for (int j = 0; j < 8; ++j) pp[j] = u.peer_slab_b[r] + off + (long long)min(j, u.n_rt - 1) * stride;
+          load16_sys_x8(pv, pp);
+          f32x4 gsum = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 1; r < IQLHIP_MAX_WORLD; ++r) if (r < u.n_peer) gr += pv[r];
+          for (int j = 0; j < 8; ++j) if (j < u.n_rt) gsum += pv[j];
+          gr = (r == 0) ? gsum : gr + gsum;
+        }
+      } else {
+        f32x4 pv[8];
+        const float* pp[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pp[r] = u.peer_flat[min(r, u.n_peer - 1)] + e;
+        load16_sys_x8(pv, pp);
+        gr = pv[0];
+#pragma unroll
+        for (int r = 1; r < IQLHIP_MAX_WORLD; ++r) if (r < u.n_peer) gr += pv[r];
+      }
     } else if (u.flat_grads) gr = *(const f32x4*)(u.flat_grads + e);
     else gr = slab_grad(u, e, net);
     const int grp = (net == IQLHIP_NET_V) ? 0 : ((net == IQLHIP_NET_PI) ? 2 : 1);
@@ -1771,7 +1798,20 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float l[3];
-    if (PEER) {
+    const float sc_ib = FROM_TABLE ? u.sched[u.sched_idx].inv_batch : u.sc.inv_batch;
+    if (PEER && u.peer_direct) {
+      // per rank the tail words its flatten kernel would have written (one chunk: loss_parts[k * 64]), summed in rank order
+      const float ib = sc_ib;
+      f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < u.n_peer; ++r) {
+        float s4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s4[k] = 0.f + __hip_atomic_load(u.peer_loss[r] + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const f32x4 tr = (f32x4){s4[0] * ib, (s4[1] * ib + s4[2] * ib) * 0.5f, s4[3] * ib, 0.f};
+        t = (r == 0) ? tr : t + tr;
+      }
+      l[0] = t[0]; l[1] = t[1]; l[2] = t[2];
+    } else if (PEER) {
       f32x4 t = load16_sys(u.peer_flat[0] + u.L.n_params);
       for (int r = 1; r < u.n_peer; ++r) t += load16_sys(u.peer_flat[r] + u.L.n_params);
       l[0] = t[0]; l[1] = t[1]; l[2] = t[2];
