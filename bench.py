@@ -19,7 +19,7 @@ N > 1: BASELINE.json configs[3] (obs=17, act=6, 10M-row buffer replicated per GP
        Launched without torch.distributed.run (WORLD_SIZE unset), `--gpus N` spawns the N rank processes itself.
 
 The timed region never contains a graph capture or instantiation for ANY --steps/--warmup: the library composes a
-run from replays of one 64-step chunk graph (captured, instantiated and uploaded by prepare_train_steps before
+run from replays of two fixed chunk graphs (64 and 16 steps; captured, instantiated and rehearsed by prepare_train_steps before
 the warm-up) plus directly launched steps.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) with `roofline` (the backward kernel, the step's
@@ -222,6 +222,9 @@ def run_rank(args, world: int) -> int:
         want = args.exchange
         tr.enable_data_parallel(exchange={"auto": "both", "rccl": "rccl", "p2p": "p2p"}[want])
         modes = ["p2p", "rccl"] if want == "auto" else [want]
+        if want == "auto" and tr._dp_exchange != "p2p":      # peer mapping failed somewhere: the collective library only
+            modes = ["rccl"]
+            probe["p2p"] = {"unavailable": getattr(tr, "_p2p_error", "attach failed")}
         for m in modes:
             tr.select_exchange(m)
             tr.prepare_train_steps(buf, B)
@@ -229,13 +232,15 @@ def run_rank(args, world: int) -> int:
             # the warm-up steps are split between the two exchanges and timed; the faster one that kept the replicas
             # bit-identical runs the timed region.  (Too few warm-up steps to tell: RCCL, the vendor's collective.)
             half = warm // 2
-            if half >= 8:
+            if len(modes) == 1:
+                exchange = modes[0]
+            elif half >= 8:
                 for m in modes:
                     tr.select_exchange(m)
                     t = timed(half)
                     probe[m] = {"steps_per_s": round(half * world / t, 1), "replicas_equal": replicas_equal()}
                 warm -= 2 * half
-                ok = [m for m in modes if probe[m]["replicas_equal"]]
+                ok = [m for m in modes if probe[m].get("replicas_equal")]
                 exchange = max(ok, key=lambda m: probe[m]["steps_per_s"]) if ok else "rccl"
             else:
                 exchange = "rccl"

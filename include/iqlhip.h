@@ -134,6 +134,10 @@ int iqlhip_set_precision(iqlhip_ctx* ctx, int mode);
  * iql.py:331-333, active while the actor is in train mode): p in [0,1), 0 = off.  Keep-masks are drawn on
  * the device (Philox4x32-10 keyed by `seed` and a per-step counter). */
 int iqlhip_set_dropout(iqlhip_ctx* ctx, float p, uint64_t seed);
+/* The context's Philox stream positions {dropout step, act() call}: read them from a context that is about to be
+ * replaced and set them on its successor, so that neither random stream restarts mid-run. */
+int iqlhip_get_counters(const iqlhip_ctx* ctx, uint64_t out[2]);
+int iqlhip_set_counters(iqlhip_ctx* ctx, const uint64_t in[2]);
 /* Tests: inject keep-bits for the next steps instead of drawing them ([rows][8] uint32 per layer, bit j of
  * word w = hidden unit 32w + j); cleared by the next iqlhip_set_dropout. */
 int iqlhip_debug_write_masks(iqlhip_ctx* ctx, const uint32_t* keep0_host, const uint32_t* keep1_host, int32_t rows,

@@ -367,6 +367,21 @@ extern "C" int iqlhip_set_precision(iqlhip_ctx* c, int mode) {
   return IQLHIP_OK;
 }
 
+// The context's two Philox stream positions: {dropout step, act() call}.  A caller that replaces a context (the shim
+// re-creates it when a larger batch arrives) carries them over so that neither stream replays from its beginning.
+extern "C" int iqlhip_get_counters(const iqlhip_ctx* c, uint64_t out[2]) {
+  if (!c || !out) return fail(IQLHIP_EINVAL, "NULL argument");
+  out[0] = c->drop_step;
+  out[1] = c->act_calls;
+  return IQLHIP_OK;
+}
+extern "C" int iqlhip_set_counters(iqlhip_ctx* c, const uint64_t in[2]) {
+  if (!c || !in) return fail(IQLHIP_EINVAL, "NULL argument");
+  c->drop_step = in[0];
+  c->act_calls = in[1];
+  return IQLHIP_OK;
+}
+
 extern "C" int iqlhip_set_dropout(iqlhip_ctx* c, float p, uint64_t seed) {
   if (!c) return fail(IQLHIP_EINVAL, "NULL ctx");
   if (!(p >= 0.f && p < 1.f)) return fail(IQLHIP_EINVAL, "dropout probability must be in [0,1)");

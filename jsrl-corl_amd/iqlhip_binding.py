@@ -74,6 +74,8 @@ SYMBOLS = [
     ("iqlhip_bind", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("iqlhip_set_precision", C.c_int, [C.c_void_p, C.c_int]),
     ("iqlhip_set_dropout", C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
+    ("iqlhip_get_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("iqlhip_set_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("iqlhip_debug_write_masks", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("iqlhip_step", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(StepScalars), C.c_void_p]),
     ("iqlhip_online_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,

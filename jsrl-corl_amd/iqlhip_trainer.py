@@ -167,6 +167,10 @@ class ImplicitQLearning:
         h = self._hyper_struct()
         ctx = C.c_void_p()
         hb.check(hb.lib().iqlhip_create(C.byref(d), C.byref(h), dev.index, C.byref(ctx)))
+        if self._ctx is not None:       # carry the Philox stream positions (dropout masks, act() noise) over
+            ctr = (C.c_uint64 * 2)()
+            hb.check(hb.lib().iqlhip_get_counters(self._ctx, ctr))
+            hb.check(hb.lib().iqlhip_set_counters(ctx, ctr))
         self._release()                 # the previous (smaller) context, only now that the new one exists
         self._ctx = ctx
         self._table_cache = None
@@ -695,14 +699,34 @@ class ImplicitQLearning:
         if exchange in ("p2p", "both"):
             if world > hb.IQLHIP_MAX_WORLD:
                 raise ValueError(f"the p2p exchange serves one node (<= {hb.IQLHIP_MAX_WORLD} ranks), got {world}")
+            # collective-safe: every rank exports, gathers and TRIES to map its peers; the outcome is agreed on before
+            # anyone relies on it, so a rank whose mapping failed (no peer access between two GPUs) cannot leave the
+            # others waiting for its flags
+            err = None
             h = (C.c_char * hb.IQLHIP_IPC_HANDLE_BYTES)()
-            hb.check(lib.iqlhip_p2p_export(self._ctx, h, rank, world))
+            try:
+                hb.check(lib.iqlhip_p2p_export(self._ctx, h, rank, world))
+            except Exception as e:          # noqa: BLE001 - reported below, after the collective
+                err = e
             handles = [None] * world
-            dist.all_gather_object(handles, bytes(h.raw), group=process_group)
-            blob = C.create_string_buffer(b"".join(handles), world * hb.IQLHIP_IPC_HANDLE_BYTES)
-            hb.check(lib.iqlhip_p2p_attach(self._ctx, blob, int(timeout_ms)))
-            dist.barrier(group=process_group)       # every rank has mapped every block before anyone signals
-            self._dp_exchange = "p2p"
+            dist.all_gather_object(handles, None if err is not None else bytes(h.raw), group=process_group)
+            if err is None and all(x is not None for x in handles):
+                blob = C.create_string_buffer(b"".join(handles), world * hb.IQLHIP_IPC_HANDLE_BYTES)
+                try:
+                    hb.check(lib.iqlhip_p2p_attach(self._ctx, blob, int(timeout_ms)))
+                except Exception as e:      # noqa: BLE001
+                    err = e
+            oks = [None] * world
+            dist.all_gather_object(oks, err is None, group=process_group)   # (doubles as the barrier: all blocks mapped)
+            if all(oks):
+                self._dp_exchange = "p2p"
+            else:
+                if self._dp_exchange == "rccl":          # "both": keep the collective library's exchange
+                    hb.check(lib.iqlhip_xch_select(self._ctx, hb.XCH_RCCL))
+                    self._p2p_error = f"p2p exchange unavailable on ranks {[i for i, o in enumerate(oks) if not o]}: {err}"
+                else:
+                    raise RuntimeError(f"iqlhip: p2p exchange could not be attached on ranks "
+                                       f"{[i for i, o in enumerate(oks) if not o]}: {err}")
 
     def select_exchange(self, exchange: str) -> None:
         """Switch between attached in-library exchanges ("rccl" / "p2p"); collective: every rank must do the same."""

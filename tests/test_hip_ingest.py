@@ -139,3 +139,36 @@ def test_online_step_equals_add_sample_train():
             assert np.array_equal(aa, ab)            # the mean action: same kernels, same weights
         else:                                        # training mode: each trainer draws from its own Philox stream position
             assert np.all(np.abs(ab) <= 1.0) and tr_b._ctx is not None
+
+
+def test_batch_growth_keeps_random_stream_positions_and_survives_a_refused_size():
+    """Growing the batch re-creates the library context: the dropout-mask and act()-noise stream positions carry over
+    (the streams do not replay from their beginning), and a size the library refuses leaves the trainer usable."""
+    import ctypes as C
+    import iqlhip_binding as hb
+    from hip_helpers import build_hip_trainer, to_torch_batch
+    S, A = 17, 6
+    params = synth.synth_params(S, A, seed=151)
+    hyper = {"iql_tau": 0.7, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    tr = build_hip_trainer(params, S, A, True, hyper, {"v": 3e-4, "q": 3e-4, "pi": 3e-4}, 1000, dropout=0.1)
+
+    def batch(B, seed):
+        d = synth.synth_transitions(B, S, A, seed=seed)
+        return to_torch_batch({"s": d["observations"], "a": d["actions"], "r": d["rewards"], "ns": d["next_observations"],
+                               "d": d["terminals"]})
+
+    for k in range(3):
+        tr.train(batch(256, k))
+    tr.actor.act(np.zeros(S, dtype=np.float32), "cuda")      # eval/train-mode call counts are the library's own
+    ctr = (C.c_uint64 * 2)()
+    hb.check(hb.lib().iqlhip_get_counters(tr._ctx, ctr))
+    before = (int(ctr[0]), int(ctr[1]))
+    assert before[0] == 3
+    tr.train(batch(512, 9))                                   # grows: a new context behind the same trainer
+    assert tr._max_batch == 512
+    hb.check(hb.lib().iqlhip_get_counters(tr._ctx, ctr))
+    assert int(ctr[0]) == before[0] + 1 and int(ctr[1]) == before[1]
+    with pytest.raises(ValueError):
+        tr.reserve_batch(1 << 20)                             # beyond the library's range: refused up front
+    log = tr.train(batch(256, 10))                            # ... and the existing context still trains
+    assert all(np.isfinite(v) for v in log.values())
