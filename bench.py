@@ -330,8 +330,13 @@ def run_rank(args, world: int) -> int:
         except AttributeError:
             ncpu = os.cpu_count() or 1
         cpu_rows = min(rows, 1_000_000)
+        # threads: 1 and the box's CPU share for one GPU (16; os.sched_getaffinity reports every core of the host, but a
+        # 1-GPU box is limited to 16 CPUs' worth of time — oversubscribing that with hundreds of OpenMP threads stalls)
+        thr_many = min(ncpu, 16)
         runs = []
-        for thr in sorted({1, min(ncpu, 16), ncpu}):
+        for thr in sorted({1, thr_many}):
+            sys.stderr.write(f"bench.py: cpu_baseline on {thr} thread(s), {args.cpu_seconds:.0f} s ...\n")
+            sys.stderr.flush()
             sps, n, el = port.time_cpu_steps(S, A, B, cpu_rows, seconds_budget=args.cpu_seconds, threads=thr)
             runs.append((sps, thr, n, el))
         best, cores, _, _ = max(runs)
@@ -339,7 +344,7 @@ def run_rank(args, world: int) -> int:
             "value": round(best, 2), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"PyTorch-CPU port of the reference step (oracle/iql_torch_port.py), same S/A/B, {cpu_rows}-row buffer: "
                       + "; ".join(f"{n} steps in {el:.1f}s @{thr} thread(s) = {sps:.1f}/s" for sps, thr, n, el in runs)
-                      + f"; torch {torch.__version__}, {ncpu} host cpus available to the process"}
+                      + f"; torch {torch.__version__}; the process may run on {ncpu} host cpus, of which a 1-GPU box grants 16"}
         out["speedup_vs_cpu"] = round(value / best, 1)
     print(json.dumps(out), flush=True)
     if world > 1:
