@@ -372,16 +372,26 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       const float* wl[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) wl[ct] = W0s + (wave * 64 + ct * 16 + l15) * k0;
+      // columns kk >= k0 of a packed row hold other fields: they are zeroed on the X side (2 selects per k-step, made
+      // here, in the read phase); the weight operand is read with a clamped column and used as it is (finite x 0 = 0).
+      // With the selects on the four weight operands the compiler sank each v_cndmask in front of its MFMA pair
+      // (VALU write -> s_nop -> MFMA, 24 times): the 48 MFMAs of this phase took 2.25 k cycles instead of 1.5 k.
       float bq[8][4], aq[8][2];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + g;
         const int kc = min(kk, k0 - 1);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { const float v = wl[ct][kc]; bq[ks][ct] = (kk < k0) ? v : 0.f; }
-        aq[ks][0] = x0[kc];
-        aq[ks][1] = x1[kc];
+        for (int ct = 0; ct < 4; ++ct) bq[ks][ct] = wl[ct][kc];
+        const float xa = x0[kc], xb_ = x1[kc];
+        aq[ks][0] = (kk < k0) ? xa : 0.f;
+        aq[ks][1] = (kk < k0) ? xb_ : 0.f;
       }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {      // (pin the selected values: no re-evaluation next to the MFMAs)
+        asm volatile("" : "+v"(aq[ks][0]), "+v"(aq[ks][1]));
+      }
+      STAMP(p, 5);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         if (ks < nks) {
@@ -392,6 +402,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
           }
         }
       }
+      STAMP(p, 6);
     } else if (w0_lds) {
       const float* wl[4];
 #pragma unroll
@@ -458,6 +469,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       }
     }
   }
+  STAMP(p, 7);
   __syncthreads();
   STAMP(p, 2);
 
@@ -490,15 +502,26 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
         acc1 = MFMA_BF16(a, b1, acc1);
       }
     } else {
+      // software pipeline: the H0 operands of k-step ks+1 are read from LDS BEFORE the 8 MFMAs of k-step ks issue
+      // (hipcc placed each pair of reads directly in front of its first use: ~120 exposed cycles per 16 MFMAs)
+      f32x4 a0 = *(const f32x4*)(H0s + l15 * H0_LD + 4 * g);
+      f32x4 a1 = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 4 * g);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        const f32x4 a0 = *(const f32x4*)(H0s + l15 * H0_LD + 16 * ks + 4 * g);
-        const f32x4 a1 = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 16 * ks + 4 * g);
+        f32x4 a0n = a0, a1n = a1;
+        if (ks + 1 < 16) {
+          a0n = *(const f32x4*)(H0s + l15 * H0_LD + 16 * (ks + 1) + 4 * g);
+          a1n = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 16 * (ks + 1) + 4 * g);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the reads above are issued here, not after the MFMAs below
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           acc0 = MFMA16(bw[ks][t], a0[t], acc0);
           acc1 = MFMA16(bw[ks][t], a1[t], acc1);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = a0n;
+        a1 = a1n;
       }
     }
     f32x4 h0, h1;
@@ -1359,16 +1382,27 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           }
         }
       } else {
+        // (software pipeline as in the forward's layer 1: the dH1 operands of k-step ks+1 are read before the 8 MFMAs
+        //  of k-step ks issue)
+        float a0 = dH1s[l15 * H0_LD + 64 * wave + g];
+        float a1 = dH1s[(16 + l15) * H0_LD + 64 * wave + g];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          const int kk = 64 * wave + 4 * ks + g;
-          const float a0 = dH1s[l15 * H0_LD + kk];
-          const float a1 = dH1s[(16 + l15) * H0_LD + kk];
+          float a0n = a0, a1n = a1;
+          if (ks + 1 < 16) {
+            const int kk = 64 * wave + 4 * (ks + 1) + g;
+            a0n = dH1s[l15 * H0_LD + kk];
+            a1n = dH1s[(16 + l15) * H0_LD + kk];
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int tb = 0; tb < 4; ++tb) {
             acc[0][tb] = MFMA16(a0, bw[ks][tb], acc[0][tb]);
             acc[1][tb] = MFMA16(a1, bw[ks][tb], acc[1][tb]);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          a0 = a0n;
+          a1 = a1n;
         }
       }
       float* myred = red + wave * 32 * T64_LD;
