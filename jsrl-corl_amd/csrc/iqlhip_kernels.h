@@ -24,6 +24,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 #define HID 256
 #define RT_ROWS 32          // rows per forward / (b) block
@@ -502,26 +503,15 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
         acc1 = MFMA_BF16(a, b1, acc1);
       }
     } else {
-      // software pipeline: the H0 operands of k-step ks+1 are read from LDS BEFORE the 8 MFMAs of k-step ks issue
-      // (hipcc placed each pair of reads directly in front of its first use: ~120 exposed cycles per 16 MFMAs)
-      f32x4 a0 = *(const f32x4*)(H0s + l15 * H0_LD + 4 * g);
-      f32x4 a1 = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 4 * g);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        f32x4 a0n = a0, a1n = a1;
-        if (ks + 1 < 16) {
-          a0n = *(const f32x4*)(H0s + l15 * H0_LD + 16 * (ks + 1) + 4 * g);
-          a1n = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 16 * (ks + 1) + 4 * g);
-        }
-        __builtin_amdgcn_sched_barrier(0);      // the reads above are issued here, not after the MFMAs below
+        const f32x4 a0 = *(const f32x4*)(H0s + l15 * H0_LD + 16 * ks + 4 * g);
+        const f32x4 a1 = *(const f32x4*)(H0s + (16 + l15) * H0_LD + 16 * ks + 4 * g);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           acc0 = MFMA16(bw[ks][t], a0[t], acc0);
           acc1 = MFMA16(bw[ks][t], a1[t], acc1);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = a0n;
-        a1 = a1n;
       }
     }
     f32x4 h0, h1;
@@ -899,7 +889,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         float wv[8];
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) wv[cc] = wS[r8 + 32 * cc];
-        for (int e = 0; 8 * e < Dp; ++e) {
+        const int DpZ = (D <= 8) ? 8 : Dp;      // dims the dH1 / dW2 products read as operands (zero-filled beyond A)
+        for (int e = 0; 8 * e < DpZ; ++e) {
           const int dd = sub + 8 * e;
           float dyv[8], dlv[8];
 #pragma unroll
@@ -968,29 +959,60 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ts += red[k * 64 + tid]; tl += red[k * 64 + 32 + tid]; }
         slab[go.b2 + tid] = ts;
-        if (gls) {
-          const float lsr = p.log_std[tid];
+        if (gls) {     // (lsr: this lane's raw log_std, loaded at the top of the block — tid < D <= 32 is lane tid of wave 0;
+                       //  a load issued HERE would queue behind the whole activation-tile stream)
           const bool inside = (lsr >= p.hy.log_std_min) && (lsr <= p.hy.log_std_max);
           slab[go.log_std + tid] = inside ? tl * p.inv_batch : 0.f;
         }
       }
+    } else if (designated && net != IQLHIP_NET_PI) {
+      // scalar heads (V, Q1, Q2; D = 1): one 256-term sum by wave 0 — 4 rows per lane, then a shuffle tree.  (Kept as it is:
+      // these blocks are not the kernel's last ones, and db2 of a Q net, sum_r (q - y) / B, cancels so heavily that
+      // ANY other summation order moves it by ~2e-5 of itself against the reference's equally arbitrary order.)
+      if (wave == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += dYs[(lane + 64 * q) * DYA];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) slab[go.b2] = s;
+      }
     } else if (designated) {
-      for (int dd = wave; dd < D; dd += 4) {
-        float s = 0.f, sl = 0.f;
+      // the policy with D <= 8: thread (dim tid & 7, row group tid >> 3) sums 8 rows, the 32 partial sums per dim meet in LDS and are
+      // added in row-group order by one thread per dim (a dim per wave and pass, with a 6-level shuffle tree per dim,
+      // took 2.9 k cycles on the one block that does this — the last block of the whole kernel)
+      const bool gls = (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN);
+      const int dd = tid & 7, rg = tid >> 3;
+      // (both stages are balanced trees: these sums cancel heavily — db2 of a Q net is sum_r (q - y) / B — and a
+      //  sequential 256-term sum lost a digit against the reference: 2.1e-5 instead of 2.6e-6 on one fixture)
+      float s = 0.f, sl = 0.f;
+      if (dd < D) {
+        float a[8], b[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          s += dYs[(lane + 64 * q) * DYA + dd];
-          if (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) sl += dLs[(lane + 64 * q) * DYA + dd];
+        for (int r = 0; r < 8; ++r) {
+          a[r] = dYs[(rg * 8 + r) * DYA + dd];
+          b[r] = gls ? dLs[(rg * 8 + r) * DYA + dd] : 0.f;
         }
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        sl = ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
+      }
+      red[rg * 16 + dd] = s;
+      red[rg * 16 + 8 + dd] = sl;
+      __syncthreads();                 // (block-uniform condition)
+      if (tid < D) {
+        float u[32], w[32];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); sl += __shfl_xor(sl, o); }
-        if (lane == 0) {
-          slab[go.b2 + dd] = s;
-          if (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN) {
-            const float lsr = p.log_std[dd];
-            const bool inside = (lsr >= p.hy.log_std_min) && (lsr <= p.hy.log_std_max);
-            slab[go.log_std + dd] = inside ? sl * p.inv_batch : 0.f;
-          }
+        for (int k = 0; k < 32; ++k) { u[k] = red[k * 16 + tid]; w[k] = red[k * 16 + 8 + tid]; }
+#pragma unroll
+        for (int st = 16; st > 0; st >>= 1) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) if (k < st) { u[k] += u[k + st]; w[k] += w[k + st]; }
+        }
+        const float ts = u[0], tl = w[0];
+        slab[go.b2 + tid] = ts;
+        if (gls) {
+          const bool inside = (lsr >= p.hy.log_std_min) && (lsr <= p.hy.log_std_max);
+          slab[go.log_std + tid] = inside ? tl * p.inv_batch : 0.f;
         }
       }
     }
@@ -1021,7 +1043,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       f32x4 pre[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) { pre[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; pre[t][1] = pre[t][0]; }
-      if (Dp == 16) dh1_mfma<4>(pre, dYs, W2s, DYA, wave, g, l15);
+      // k-steps of 4 action dims, rounded up to 2 / 4 / 8 (dims 4 NK .. are zero operands: not multiplied at all)
+      if (D <= 8) dh1_mfma<2>(pre, dYs, W2s, DYA, wave, g, l15);
+      else if (D <= 16) dh1_mfma<4>(pre, dYs, W2s, DYA, wave, g, l15);
       else dh1_mfma<8>(pre, dYs, W2s, DYA, wave, g, l15);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
@@ -1382,27 +1406,16 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           }
         }
       } else {
-        // (software pipeline as in the forward's layer 1: the dH1 operands of k-step ks+1 are read before the 8 MFMAs
-        //  of k-step ks issue)
-        float a0 = dH1s[l15 * H0_LD + 64 * wave + g];
-        float a1 = dH1s[(16 + l15) * H0_LD + 64 * wave + g];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          float a0n = a0, a1n = a1;
-          if (ks + 1 < 16) {
-            const int kk = 64 * wave + 4 * (ks + 1) + g;
-            a0n = dH1s[l15 * H0_LD + kk];
-            a1n = dH1s[(16 + l15) * H0_LD + kk];
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          const int kk = 64 * wave + 4 * ks + g;
+          const float a0 = dH1s[l15 * H0_LD + kk];
+          const float a1 = dH1s[(16 + l15) * H0_LD + kk];
 #pragma unroll
           for (int tb = 0; tb < 4; ++tb) {
             acc[0][tb] = MFMA16(a0, bw[ks][tb], acc[0][tb]);
             acc[1][tb] = MFMA16(a1, bw[ks][tb], acc[1][tb]);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          a0 = a0n;
-          a1 = a1n;
         }
       }
       float* myred = red + wave * 32 * T64_LD;
@@ -1462,31 +1475,31 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         }
       }
       STAMP(p, 12);
-      // stage the [64 i][k0] tile (and db0[64]) in LDS (the cross-wave buffer is free now), then flat float4 stores
-      float* T = red;                 // [64][k0]
-      float* Tb = red + 64 * IQLHIP_MAX_INPUT;   // [64]
+      // straight from the accumulators into the row-tile slab: a lane's 4 registers of a tile are 4 consecutive kc of one
+      // i, i.e. 16 contiguous bytes of the [i][kc] slab (4-byte aligned: k0 is odd as often as not) — one unaligned
+      // 16-byte store where the whole run lies below k0, single words around the k0 column (= db0).  Staging the tile in
+      // LDS for aligned float4 stores cost a barrier and two passes (1.8 k cycles of every (b) block's tail).
+      {
+        float* dstW = slabB + i0 * k0;
+        float* dstB = slabB + HID * k0 + i0;
+        const int il = 16 * wave + l15;
 #pragma unroll
-      for (int ct = 0; ct < 9; ++ct) {
-        if (ct < nct) {
+        for (int ct = 0; ct < 9; ++ct) {
+          if (ct < nct) {
+            const int kc0 = 16 * ct + 4 * g;
+            if (kc0 + 3 < k0) {
+              *(f32x4u*)(dstW + (unsigned)(il * k0 + kc0)) = acc[ct];
+            } else {
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int kc = 16 * ct + 4 * g + reg;
-            const int il = 16 * wave + l15;
-            if (kc < k0) T[il * k0 + kc] = acc[ct][reg];
-            else if (kc == k0) Tb[il] = acc[ct][reg];
+              for (int reg = 0; reg < 4; ++reg) {
+                const int kc = kc0 + reg;
+                if (kc < k0) dstW[(unsigned)(il * k0 + kc)] = acc[ct][reg];
+                else if (kc == k0) dstB[il] = acc[ct][reg];
+              }
+            }
           }
         }
       }
-    }
-    __syncthreads();
-    STAMP(p, 13);
-    {
-      const float* T = red;
-      const float* Tb = red + 64 * IQLHIP_MAX_INPUT;
-      float* dst = slabB + i0 * k0;      // 64*k0 contiguous floats, 16-B aligned (i0 % 16 == 0)
-      const int nf4 = 16 * k0;                       // = 64*k0/4
-      for (int f = tid; f < nf4; f += 256) *(f32x4*)(dst + 4 * f) = *(const f32x4*)(T + 4 * f);
-      if (tid < 16) *(f32x4*)(slabB + HID * k0 + i0 + 4 * tid) = *(const f32x4*)(Tb + 4 * tid);
     }
     STAMP(p, 9);
     RT_STAMP(p, 14, rt_entry_);
