@@ -1125,7 +1125,13 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // ---- cross-wave reduction of the 32x64 tile through LDS, then coalesced store.  The extras (db1 / dW2 partial
     // sums of the 4 waves) are staged in the same pass, in the dLs region — only the loss-sum block (it == 2), which
     // has no extras, ever uses that region — so one barrier serves both reductions.
-    float* ex = dLs;   // [4 waves][(1 + Dp) rows][32 cols]
+    // exA [4 waves x 4 lane groups][2 rows: db1, scalar dW2][32 cols]: every lane stores its own partial sums — the
+    // sums over the lane groups g and over the waves are formed after the barrier, in the order ((g0+g1)+(g2+g3)) per
+    // wave, ((w0+w1)+(w2+w3)) over the waves, i.e. the sums the two shuffle steps per value used to form before the
+    // barrier (4 values x 2 dependent cross-lane steps: ~1.2 k cycles of every block that owns extras).
+    // exB [4 waves][Dp rows][32 cols]: the MFMA tiles of a wide head's dW2.
+    float* exA = dLs;
+    float* exB = dLs + 1024;
     {
       float* myred = red + wave * 32 * T64_LD;
 #pragma unroll
@@ -1138,27 +1144,16 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         }
     }
     if (extras) {
-      // db1 and dW2: reduce over g (lanes with equal l15) here, over the waves after the barrier
-#pragma unroll
-      for (int ta = 0; ta < 2; ++ta) {
-        float v = db1a[ta];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (g == 0) ex[(wave * 33 + 0) * 32 + 2 * l15 + ta] = v;
-        if (D == 1) {
-          float u = dw2a[ta];
-          u += __shfl_xor(u, 16);
-          u += __shfl_xor(u, 32);
-          if (g == 0) ex[(wave * 33 + 1) * 32 + 2 * l15 + ta] = u;
-        }
-      }
+      float* mine = exA + (wave * 4 + g) * 64 + 2 * l15;
+      *(f32x2*)mine = (f32x2){db1a[0], db1a[1]};
+      if (D == 1) *(f32x2*)(mine + 32) = (f32x2){dw2a[0], dw2a[1]};
       if (D > 1 && do_dw2) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
           if (dt < ndt)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
-              ex[(wave * 33 + 1 + 16 * dt + 4 * g + reg) * 32 + 2 * l15 + tb_own] = acc2[dt][0][reg];
+              exB[(wave * 32 + 16 * dt + 4 * g + reg) * 32 + 2 * l15 + tb_own] = acc2[dt][0][reg];
       }
     }
     __syncthreads();
@@ -1177,8 +1172,19 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     if (extras) {
       for (int e = tid; e < (1 + D) * 32; e += 256) {
         const int rr = e >> 5, jj = e & 31;
-        const float s = (ex[(0 * 33 + rr) * 32 + jj] + ex[(1 * 33 + rr) * 32 + jj]) +
-                        (ex[(2 * 33 + rr) * 32 + jj] + ex[(3 * 33 + rr) * 32 + jj]);
+        float s;
+        if (rr == 0 || D == 1) {
+          float wsum[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float* a = exA + (w * 4) * 64 + rr * 32 + jj;
+            wsum[w] = (a[0] + a[64]) + (a[128] + a[192]);
+          }
+          s = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        } else {
+          const float* b = exB + (rr - 1) * 32 + jj;
+          s = (b[0] + b[1024]) + (b[2048] + b[3072]);
+        }
         if (rr == 0) { if (do_db1) slab[go.b1 + j0 + jj] = s; }
         else if (do_dw2 && (D == 1 || (jj & 1) == tb_own)) slab[go.w2 + (rr - 1) * HID + j0 + jj] = s;
       }
