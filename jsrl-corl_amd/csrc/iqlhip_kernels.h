@@ -319,10 +319,6 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   // (d) this wave's W1 rows (16 output units x 256 k) as MFMA fragments: 64 KiB per block
   const int n1 = ns * 64 + wave * 16 + l15;  // hidden-1 unit of this lane
   f32x4 bw[16];
-  if (!w0_dma) {
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + (unsigned)(n1 * HID + 16 * ks + 4 * g));
-  }
 
   xr_store(xr, Xr, n_x);
   const int Dp = (D + 15) & ~15;
@@ -349,7 +345,10 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     }
   }
   __syncthreads();
-  if (w0_dma) {
+  // the W1 fragments are requested only now: 16 x 1 KB per wave of row-fragment loads take ~1.5 k cycles of the CU's
+  // one vector-memory pipe just to ISSUE — in front of the barrier they delayed layer 0 by that much; here they
+  // stream in under layer 0's 4 k cycles
+  {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + (unsigned)(n1 * HID + 16 * ks + 4 * g));
   }
@@ -1265,11 +1264,10 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       const unsigned row = (unsigned)BROW(row0 + (f >> 6));   // rows >= B: dY = 0 -> dH1 = 0
       h1v[q] = *(const f32x4*)(H1g + (row * (unsigned)HID + (unsigned)(4 * (f & 63))));
     }
-    // W1 fragments: k = j in [64*wave, +64), n = i0 + 4*l15 + t
+    // W1 fragments: k = j in [64*wave, +64), n = i0 + 4*l15 + t — requested after the dY barrier (below): 16 KiB
+    // per wave of fragment-shaped loads take ~1.5 k cycles of the CU's vector-memory pipe to issue, which in front of
+    // the loss arithmetic only delayed it; issued there they stream in under the dH1 tile phase
     f32x4 bw[16];
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      bw[ks] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * ks + g) * HID + i0 + 4 * l15));
     // H0 mask slice [32][64] as float4 f = tid + 256q: row f>>4, cols i0 + 4*(f&15)
     f32x4 h0v[2];
 #pragma unroll
@@ -1313,6 +1311,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     }
     __syncthreads();
     STAMP(p, 5);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      bw[ks] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * ks + g) * HID + i0 + 4 * l15));
 
     // dH1s[r][j] = (sum_dd dY[r][dd] W2[dd][j]) * (H1[r][j] > 0)
     if (D > 8) {

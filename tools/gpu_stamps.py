@@ -92,6 +92,7 @@ def xcd_spans(name, blocks, last):
 
 n_rt = (B + 31) // 32
 fwd_blocks = np.arange(8 * n_rt * 4)
+report("fwd prologue", fwd_blocks, [(8, "stamp cost"), (9, "issue all loads"), (10, "wait X rows + LDS store"), (11, "wait W2/W0 + LDS stores"), (1, "barrier")])
 report("fwd", fwd_blocks, [(1, "prefetch+gather"), (5, "L0: LDS operand reads"), (6, "L0: MFMAs"), (7, "L0: epilogue + H0 writes"), (2, "L0: barrier"), (3, "H0 save + layer1"), (4, "H1 save + head")])
 n_chunk = (B + 255) // 256
 per_net = 32 * n_chunk + 4 * n_rt
