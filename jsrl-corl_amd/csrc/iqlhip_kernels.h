@@ -145,6 +145,10 @@ struct StepParams {
   // policy-inference entry point iqlhip_actor_forward; -1: the training forward over all 7 instances
   int only_inst;
   int w0_lds_k;             // instances with k_in <= this stage their layer-0 weights in LDS
+  // log2 of the column slices a forward block walks (0, 1, 2): grid = 8 x row tiles x (NSPLIT >> fwd_spb_l2).  Batches of
+  // more row tiles than the chip has CUs take 2 or 4 slices per block: layer 0 and the block prologue are then paid
+  // once per 2 / 4 slices instead of once per slice (host: launch_fwd).
+  int fwd_spb_l2;
   // next step's batch (hipGraph chunks): the forward's idle blocks (blockIdx & 7 == 7, one per row tile and column
   // slice) copy rows[idx[r]] -> g_xb[r] (whole padded rows) into the OTHER staging buffer while the 7 instances run.
   // In the update kernel the two dependent HBM round trips (index, then row) stretched that kernel by ~0.8 us.
@@ -217,7 +221,7 @@ __device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld
 // W0DMA: the variant that may stage wide layer-0 weights by LDS-DMA.  A separate instantiation because the mere
 // presence of an LDS-DMA makes the compiler wait vmcnt(0) before LDS reads on every path it may reach (measured:
 // +1 us on the narrow-input configs, whose W1 prefetch then no longer streams under layer 0).
-template <bool BF16, bool W0DMA>
+template <bool BF16, bool W0DMA, bool MULTI>
 __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   RT_ENTRY();
   const int bid = blockIdx.x;
@@ -227,8 +231,10 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     if (p.g_idx) gather_rows_flat(p.g_rows, p.g_ld, p.g_idx, p.g_xb, p.g_n, rest * 256 + (int)threadIdx.x, (int)(gridDim.x >> 3) * 256);
     return;
   }
-  const int ns = rest & (NSPLIT - 1);
-  const int rt = rest >> 2;
+  const int spb_l2 = MULTI ? p.fwd_spb_l2 : 0;      // (MULTI = false: exactly the one-slice code, no loop)
+  const int spb = 1 << spb_l2;
+  int ns = (rest & ((NSPLIT >> spb_l2) - 1)) << spb_l2;       // first (or only) column slice of this block
+  const int rt = rest >> (2 - spb_l2);
   const int row0 = rt * RT_ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   f32x4 bias0[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) bias0[ct] = *(const f32x4*)(np.b0 + (unsigned)(wave * 64 + ct * 16 + 4 * g));
-  const f32x4 bias1 = *(const f32x4*)(np.b1 + (unsigned)(ns * 64 + wave * 16 + 4 * g));
+  f32x4 bias1 = *(const f32x4*)(np.b1 + (unsigned)(ns * 64 + wave * 16 + 4 * g));
   // (b2) dropout keep-bits of this row tile (policy instance only): thread -> (row tid >> 3, word tid & 7)
   const bool drop = (inst == 6) && (p.drop_bits != nullptr);
   unsigned mk0 = 0xFFFFFFFFu, mk1 = 0xFFFFFFFFu;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     }
   }
   // (d) this wave's W1 rows (16 output units x 256 k) as MFMA fragments: 64 KiB per block
-  const int n1 = ns * 64 + wave * 16 + l15;  // hidden-1 unit of this lane
+  int n1 = ns * 64 + wave * 16 + l15;  // hidden-1 unit of this lane
   f32x4 bw[16];
 
   xr_store(xr, Xr, n_x);
@@ -404,33 +410,54 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       }
       STAMP(p, 6);
     } else if (w0_lds) {
+      // wide inputs (9..24 k-steps): chunks of 8 k-steps in straight-line code, the operands of a chunk read in one
+      // batch like above and the next chunk's batch issued before this chunk's MFMAs.  (As a run-time loop with a
+      // one-step look-ahead the compiler waited for each step's six reads in front of its eight MFMAs: 550 cycles
+      // per k-step instead of 256.)  Only the last k-step can reach beyond k0; the selects are made per batch.
       const float* wl[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) wl[ct] = W0s + (wave * 64 + ct * 16 + l15) * k0;
-      {
-        const int kc = min(g, k0 - 1);
+      float bqA[8][4], aqA[8][2], bqB[8][4], aqB[8][2];
+      auto rd = [&](float (&bq)[8][4], float (&aq)[8][2], const int base) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { const float v = wl[ct][kc]; bcur[ct] = (g < k0) ? v : 0.f; }
-        acur[0] = x0[kc];
-        acur[1] = x1[kc];
-      }
-      for (int ks = 0; ks < nks; ++ks) {
-        const int kn = 4 * (ks + 1) + g;       // operands of the next k-step (read while this one's MFMAs run)
-        const int kc = min(kn, k0 - 1);        // X columns >= k0 hold other fields: W0 = 0 there
+        for (int h = 0; h < 2; ++h) {
+          if (base + 4 * h < nks) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { const float v = wl[ct][kc]; bnxt[ct] = (kn < k0) ? v : 0.f; }
-        anxt[0] = x0[kc];
-        anxt[1] = x1[kc];
+            for (int k4 = 0; k4 < 4; ++k4) {
+              const int ks = 4 * h + k4;
+              const int kk = 4 * (base + ks) + g;
+              const int kc = min(kk, k0 - 1);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          acc[0][ct] = MFMA16(bcur[ct], acur[0], acc[0][ct]);
-          acc[1][ct] = MFMA16(bcur[ct], acur[1], acc[1][ct]);
+              for (int ct = 0; ct < 4; ++ct) bq[ks][ct] = wl[ct][kc];
+              const float xa = x0[kc], xb_ = x1[kc];
+              aq[ks][0] = (kk < k0) ? xa : 0.f;
+              aq[ks][1] = (kk < k0) ? xb_ : 0.f;
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) asm volatile("" : "+v"(aq[4 * h + k4][0]), "+v"(aq[4 * h + k4][1]));
+          }
         }
+      };
+      auto mm = [&](const float (&bq)[8][4], const float (&aq)[8][2], const int base) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) bcur[ct] = bnxt[ct];
-        acur[0] = anxt[0];
-        acur[1] = anxt[1];
-      }
+        for (int ks = 0; ks < 8; ++ks) {
+          if (base + ks < nks) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              acc[0][ct] = MFMA16(bq[ks][ct], aq[ks][0], acc[0][ct]);
+              acc[1][ct] = MFMA16(bq[ks][ct], aq[ks][1], acc[1][ct]);
+            }
+          }
+        }
+      };
+      rd(bqA, aqA, 0);
+      rd(bqB, aqB, 8);
+      STAMP(p, 5);
+      mm(bqA, aqA, 0);
+      if (nks > 16) rd(bqA, aqA, 16);
+      mm(bqB, aqB, 8);
+      if (nks > 16) mm(bqA, aqA, 16);
+      STAMP(p, 6);
     } else {
       const float* wrow[4];
 #pragma unroll
@@ -473,6 +500,11 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   __syncthreads();
   STAMP(p, 2);
 
+  // ======== per column slice: layer 1 over the block's H0 tile, head partials.  One pass when the grid holds a block
+  // per slice; 2 or 4 passes for large batches — the next slice's W1 fragments, head weights and bias are requested
+  // right after this slice's layer-1 MFMAs and arrive under its head phase.
+  for (int it = 0;; ++it) {
+  const bool more = MULTI && (it + 1 < spb);
   // save H0 columns [64*ns, +64) of the trainable instances for the backward pass
   if (slot >= 0) {
     float* dst = h0g + slot * MB * HID;
@@ -500,6 +532,11 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
                                 *(const f32x4*)(H0s + (16 + l15) * H0_LD + 32 * j + 16 + 4 * g));
         acc0 = MFMA_BF16(a, b0, acc0);
         acc1 = MFMA_BF16(a, b1, acc1);
+        if ((j & 1) && more) {      // the next slice's fragments replace the four just used (see below)
+#pragma unroll
+          for (int ks = 2 * j - 2; ks < 2 * j + 2; ++ks)
+            bw[ks] = *(const f32x4*)(np.w1 + (unsigned)((n1 + 64) * HID + 16 * ks + 4 * g));
+        }
       }
     } else {
 #pragma unroll
@@ -510,6 +547,13 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
         for (int t = 0; t < 4; ++t) {
           acc0 = MFMA16(bw[ks][t], a0[t], acc0);
           acc1 = MFMA16(bw[ks][t], a1[t], acc1);
+        }
+        // more slices to come: the next slice's W1 fragments are requested into the registers whose MFMAs have just
+        // been issued, four k-steps at a time — they arrive under the rest of this layer and the head phase
+        if ((ks & 3) == 3 && more) {
+#pragma unroll
+          for (int k2 = ks - 3; k2 <= ks; ++k2)
+            bw[k2] = *(const f32x4*)(np.w1 + (unsigned)((n1 + 64) * HID + 16 * k2 + 4 * g));
         }
       }
     }
@@ -533,6 +577,16 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
   }
   __syncthreads();
   STAMP(p, 3);
+  f32x4 bias1n = bias1;
+  if (more) {      // the next slice's head weights and bias
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = min(tid + 256 * q, D * 16 - 1);
+      w2pre[q] = *(const f32x4*)(np.w2 + (unsigned)((e >> 4) * HID + (ns + 1) * 64 + 4 * (e & 15)));
+    }
+    bias1n = *(const f32x4*)(np.b1 + (unsigned)((ns + 1) * 64 + wave * 16 + 4 * g));
+    n1 += 64;
+  }
 
   {
     const int rl = tid >> 3;
@@ -592,6 +646,16 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
       }
     }
   }
+  if (!more) break;
+  __syncthreads();      // every thread is done with this slice's H1s / W2s
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = tid + 256 * q;
+    if (e < D * 16) *(f32x4*)(W2s + (e >> 4) * W2_LD + 4 * (e & 15)) = w2pre[q];
+  }
+  bias1 = bias1n;
+  ++ns;
+  }   // (the next slice's H1s / W2s writes are ordered before their readers by the barrier after its layer 1)
   STAMP(p, 4);
   RT_STAMP(p, 14, rt_entry_);
   RT_STAMP(p, 15, iql_realtime());
