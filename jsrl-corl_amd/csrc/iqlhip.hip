@@ -120,6 +120,7 @@ struct iqlhip_ctx {
   size_t lds_fwd = 0, lds_fwd_solo = 0, lds_bwd = 0;
   int n_cus = 256;                    // compute units of the device (MI355X: 256)
   int w0_lds_k = 0;                   // widest layer-0 input whose weights the forward stages in LDS
+  int bwd_spb_force = -1;             // the same for the backward's (b) blocks (IQLHIP_BWD_SPB_L2)
   int fwd_spb_force = -1;             // diagnostic (IQLHIP_FWD_SPB_L2): fixed slices-per-block exponent of the forward
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
   hipStream_t cap_stream = nullptr;
@@ -275,6 +276,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   else if (ks_ <= W0_DMA_MAX_K && fits(ks_)) w0_lds_k = ks_;
   if (const char* ov = getenv("IQLHIP_W0_LDS_K")) w0_lds_k = std::min(w0_lds_k, atoi(ov));   // diagnostic (tools/): force a narrower staging
   c->w0_lds_k = w0_lds_k;
+  if (const char* ov = getenv("IQLHIP_BWD_SPB_L2")) c->bwd_spb_force = std::max(0, std::min(2, atoi(ov)));   // diagnostic (tools/)
   if (const char* ov = getenv("IQLHIP_FWD_SPB_L2")) c->fwd_spb_force = std::max(0, std::min(2, atoi(ov)));   // diagnostic (tools/)
   c->lds_fwd = fwd_fixed + (size_t)HID * w0_lds_k * sizeof(float) + (w0_lds_k > W0_LDS_MAX_K ? 4096 : 0);
   // One block per CU while the grid fits the chip (co-resident blocks share a CU's L1 and fill rate and only slow
@@ -296,10 +298,13 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
                           (const void*)iql_fwd_kernel<true, false, true>,   (const void*)iql_fwd_kernel<true, true, true>};
     for (const void* f : fwd) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
   }
-  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
-  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
-  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
-  HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  {
+    const void* bwd[8] = {(const void*)iql_bwd_kernel<false, false, false>, (const void*)iql_bwd_kernel<false, true, false>,
+                          (const void*)iql_bwd_kernel<true, false, false>,  (const void*)iql_bwd_kernel<true, true, false>,
+                          (const void*)iql_bwd_kernel<false, false, true>,  (const void*)iql_bwd_kernel<false, true, true>,
+                          (const void*)iql_bwd_kernel<true, false, true>,   (const void*)iql_bwd_kernel<true, true, true>};
+    for (const void* f : bwd) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  }
   return IQLHIP_OK;
 }
 
@@ -560,7 +565,7 @@ static size_t fwd_lds(const iqlhip_ctx* c, int n_blocks) { return (n_blocks <= c
 static void launch_fwd_grid(const iqlhip_ctx* c, const StepParams& p, int nb, hipStream_t st) {
   const bool dma = c->w0_lds_k > W0_LDS_MAX_K;       // some instance stages wide layer-0 weights by LDS-DMA
   const size_t lds = fwd_lds(c, nb);
-  const bool bf = c->precision == 1, multi = p.fwd_spb_l2 > 0;
+  const bool bf = c->precision == 1, multi = (p.spb_l2 & 3) > 0;
 #define FWD_LAUNCH(BF, DMA, MU) hipLaunchKernelGGL((iql_fwd_kernel<BF, DMA, MU>), dim3(nb), dim3(256), lds, st, p)
   if (multi) {
     if (bf) { if (dma) FWD_LAUNCH(true, true, true); else FWD_LAUNCH(true, false, true); }
@@ -574,7 +579,7 @@ static void launch_fwd_grid(const iqlhip_ctx* c, const StepParams& p, int nb, hi
 
 // Column slices per forward block (log2).  One block per (instance, row tile, slice) while that grid fits the chip in
 // one round; beyond it every extra round costs a whole block time (prologue + layer 0 + one slice), so blocks take 2
-// or 4 slices each — layer 0 and the prologue are then paid once per 2 / 4 slices (profiles/r02_forward_slices_per_block.txt).
+// or 4 slices each — layer 0 and the prologue are then paid once per 2 / 4 slices (profiles/r02_slices_per_block.txt).
 static int fwd_spb_l2(const iqlhip_ctx* c, int n_rt) {
   if (c->fwd_spb_force >= 0) return c->fwd_spb_force;
   // (two blocks sharing a CU each run ~1.8x slower — a second block per CU counts as no extra slot)
@@ -585,23 +590,38 @@ static int fwd_spb_l2(const iqlhip_ctx* c, int n_rt) {
 static void launch_fwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t st) {
   StepParams p = p_in;
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
-  p.fwd_spb_l2 = fwd_spb_l2(c, n_rt);
-  const int nb = 8 * n_rt * (NSPLIT >> p.fwd_spb_l2);
+  const int l2 = fwd_spb_l2(c, n_rt);
+  p.spb_l2 = l2;
+  const int nb = 8 * n_rt * (NSPLIT >> l2);
   launch_fwd_grid(c, p, nb, st);
 }
-static void launch_bwd(const iqlhip_ctx* c, const StepParams& p, hipStream_t st) {
+// Column slices per (b) block of the backward (log2): one while the whole grid — 4 nets x (32 dW1 tiles per 256-row
+// chunk + 4 slices per row tile) — is at most two rounds of the chip (up to 512 rows: measured equal or better), else 4:
+// the row tile's dY / dH1 tile is built once and the block's W1 fragments stream in under its MFMAs
+// (profiles/r02_slices_per_block.txt).
+static int bwd_spb_l2(const iqlhip_ctx* c, int n_chunk, int n_rt) {
+  if (c->bwd_spb_force >= 0) return c->bwd_spb_force;
+  return (4 * (32 * n_chunk + 4 * n_rt) <= 2 * c->n_cus) ? 0 : 2;
+}
+static void launch_bwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t st) {
+  StepParams p = p_in;
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   const int n_chunk = (p.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
-  const int per_net = 32 * n_chunk + 4 * n_rt;
+  const int l2 = bwd_spb_l2(c, n_chunk, n_rt);
+  p.spb_l2 = l2 << 2;
+  const int per_net = 32 * n_chunk + (4 >> l2) * n_rt;
   const dim3 grid(8 * ((per_net + 1) / 2));
   const bool full = (p.rows % CHUNK_ROWS) == 0;      // every tile of every block lies inside the batch: no clamps
-  if (c->precision == 1) {
-    if (full) hipLaunchKernelGGL((iql_bwd_kernel<true, true>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
-    else hipLaunchKernelGGL((iql_bwd_kernel<true, false>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+  const bool bf = c->precision == 1, multi = l2 > 0;
+#define BWD_LAUNCH(BF, FU, MU) hipLaunchKernelGGL((iql_bwd_kernel<BF, FU, MU>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt)
+  if (multi) {
+    if (bf) { if (full) BWD_LAUNCH(true, true, true); else BWD_LAUNCH(true, false, true); }
+    else    { if (full) BWD_LAUNCH(false, true, true); else BWD_LAUNCH(false, false, true); }
   } else {
-    if (full) hipLaunchKernelGGL((iql_bwd_kernel<false, true>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
-    else hipLaunchKernelGGL((iql_bwd_kernel<false, false>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt);
+    if (bf) { if (full) BWD_LAUNCH(true, true, false); else BWD_LAUNCH(true, false, false); }
+    else    { if (full) BWD_LAUNCH(false, true, false); else BWD_LAUNCH(false, false, false); }
   }
+#undef BWD_LAUNCH
 }
 static unsigned drop_thresh(float p) {
   const double t = (double)p * 4294967296.0;

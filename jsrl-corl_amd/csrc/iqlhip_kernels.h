@@ -145,10 +145,13 @@ struct StepParams {
   // policy-inference entry point iqlhip_actor_forward; -1: the training forward over all 7 instances
   int only_inst;
   int w0_lds_k;             // instances with k_in <= this stage their layer-0 weights in LDS
-  // log2 of the column slices a forward block walks (0, 1, 2): grid = 8 x row tiles x (NSPLIT >> fwd_spb_l2).  Batches of
+  // Bits 0..1: log2 of the column slices a forward block walks (0, 1, 2): grid = 8 x row tiles x (NSPLIT >> that).  Batches of
   // more row tiles than the chip has CUs take 2 or 4 slices per block: layer 0 and the block prologue are then paid
   // once per 2 / 4 slices instead of once per slice (host: launch_fwd).
-  int fwd_spb_l2;
+  // Bits 2..3: the same for the backward's (b) blocks (dH0 / dW0 of a row tile): the dY / dH1 tile of the 32 rows is
+  // built once and 2 or 4 of the 64-column slices are walked with it (host: launch_bwd).  (One word for both: a
+  // second one grew the kernel-argument block past 0x478 bytes and every backward launch took 0.17 us longer.)
+  int spb_l2;
   // next step's batch (hipGraph chunks): the forward's idle blocks (blockIdx & 7 == 7, one per row tile and column
   // slice) copy rows[idx[r]] -> g_xb[r] (whole padded rows) into the OTHER staging buffer while the 7 instances run.
   // In the update kernel the two dependent HBM round trips (index, then row) stretched that kernel by ~0.8 us.
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
     if (p.g_idx) gather_rows_flat(p.g_rows, p.g_ld, p.g_idx, p.g_xb, p.g_n, rest * 256 + (int)threadIdx.x, (int)(gridDim.x >> 3) * 256);
     return;
   }
-  const int spb_l2 = MULTI ? p.fwd_spb_l2 : 0;      // (MULTI = false: exactly the one-slice code, no loop)
+  const int spb_l2 = MULTI ? (p.spb_l2 & 3) : 0;      // (MULTI = false: exactly the one-slice code, no loop)
   const int spb = 1 << spb_l2;
   int ns = (rest & ((NSPLIT >> spb_l2) - 1)) << spb_l2;       // first (or only) column slice of this block
   const int rt = rest >> (2 - spb_l2);
@@ -804,13 +807,13 @@ __device__ __forceinline__ void pi_items8(const f32x4 (&hv)[8], const float (&ac
 // FULL: every row of every block's tile is a row of the batch (B % 256 == 0; the host selects the instantiation):
 // no row index is clamped, so consecutive loads differ by compile-time constants.
 #define BROW(r) (FULL ? (r) : min((r), B - 1))
-template <bool BF16, bool FULL>
+template <bool BF16, bool FULL, bool MULTI>
 __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk, int n_rt) {
   RT_ENTRY();
   const int bid = blockIdx.x;
   const int x = bid & 7;
   const int net = x & 3;
-  const int local = (bid >> 3) * 2 + (x >> 2);
+  const int local_ = (bid >> 3) * 2 + (x >> 2);
   const int n_a = 32 * n_chunk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -838,7 +841,12 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     PIN_S(p.inv_batch); PIN_S(p.hy.iql_tau); PIN_S(p.hy.beta); PIN_S(p.hy.discount); PIN_S(p.hy.exp_adv_max);
     PIN_S(n_chunk); PIN_S(n_rt);
   }
-  if (local >= n_a + 4 * n_rt) return;
+  const int bsl2 = MULTI ? ((p.spb_l2 >> 2) & 3) : 0;     // (b) blocks: log2 of the column slices per block
+  const int n_b = (4 >> bsl2) * n_rt;
+  if (local_ >= n_a + n_b) return;
+  // MULTI: the (b) blocks walk 2 / 4 slices and run 2-3x as long as a dW1 tile — they take the FIRST block indices so
+  // that the launch ends on short blocks (longest first); one-slice grids keep the dW1 tiles first
+  const int local = MULTI ? ((local_ < n_b) ? n_a + local_ : local_ - n_b) : local_;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   STAMP_BASE(p, 2048 * 16);   // second half of the stamp buffer: the forward kernel owns the first
@@ -1262,9 +1270,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   // ===================== (b): dH0 / dW0 / db0 for one 32-row tile and 64-column slice =====================
   {
     const int lb = local - n_a;
-    const int rt = lb >> 2;
-    const int is = lb & 3;
-    const int i0 = is * 64;
+    const int rt = lb >> (2 - bsl2);
+    int i0 = ((lb & ((4 >> bsl2) - 1)) << bsl2) * 64;      // first (or only) column slice of this block
     const int row0 = rt * RT_ROWS;
     const int k0 = np.k0;
     const int ld = p.ld;
@@ -1448,6 +1455,12 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     f32x4 xr[XR_MAX_F4];
     xr_load(xr, p.xb, row0 * ld / 4, n_x, x_last);
 
+    // ======== per column slice (one pass unless MULTI): dH0 slice, dW0 / db0 slice.  The next slice's W1 fragments are
+    // requested into the registers this slice's MFMAs have just consumed, its H0 mask under the MFMA phase.
+    for (int itn = 0;; ++itn) {
+    const bool more = MULTI && (itn + 1 < (1 << bsl2));
+    f32x4 h0n[2] = {h0v[0], h0v[1]};
+
     // dH0 partial over this wave's 64 j's: [32 rows][64 cols]
     {
       f32x4 acc[2][4];
@@ -1475,6 +1488,11 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
             acc[0][tb] = MFMA_BF16(A0, Bv, acc[0][tb]);
             acc[1][tb] = MFMA_BF16(A1, Bv, acc[1][tb]);
           }
+          if (more) {
+#pragma unroll
+            for (int ks = 8 * q; ks < 8 * q + 8; ++ks)
+              bw[ks] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * ks + g) * HID + i0 + 64 + 4 * l15));
+          }
         }
       } else {
 #pragma unroll
@@ -1487,6 +1505,19 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
             acc[0][tb] = MFMA16(a0, bw[ks][tb], acc[0][tb]);
             acc[1][tb] = MFMA16(a1, bw[ks][tb], acc[1][tb]);
           }
+          if ((ks & 3) == 3 && more) {
+#pragma unroll
+            for (int k2 = ks - 3; k2 <= ks; ++k2)
+              bw[k2] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * k2 + g) * HID + i0 + 64 + 4 * l15));
+          }
+        }
+      }
+      if (more) {      // the next slice's H0 mask
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int f = tid + 256 * q;
+          const unsigned row = (unsigned)BROW(row0 + (f >> 4));
+          h0n[q] = *(const f32x4*)(H0g + (row * (unsigned)HID + (unsigned)(i0 + 64 + 4 * (f & 15))));
         }
       }
       float* myred = red + wave * 32 * T64_LD;
@@ -1500,7 +1531,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         }
     }
     // park the packed rows for the dW0 product
-    xr_store(xr, Xr, n_x);
+    if (itn == 0) xr_store(xr, Xr, n_x);
     __syncthreads();
     STAMP(p, 7);
 #pragma unroll
@@ -1572,6 +1603,10 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         }
       }
     }
+    if (!more) break;
+    h0v[0] = h0n[0]; h0v[1] = h0n[1];
+    i0 += 64;
+    }   // (red / dH0s of the next slice are written behind its own barriers: every thread has left this slice's dW0 reads)
     STAMP(p, 9);
     RT_STAMP(p, 14, rt_entry_);
     RT_STAMP(p, 15, iql_realtime());
