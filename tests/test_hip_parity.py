@@ -408,6 +408,43 @@ def test_bf16_large_batch_config5_shape():
         assert np.isfinite(lb[k]) and abs(lb[k] - la[k]) <= 2e-2 * abs(la[k]), (k, la[k], lb[k])
 
 
+@pytest.mark.parametrize("S,A,B,bf16", [(17, 6, 300, False), (39, 28, 1024, False), (39, 28, 600, True)])
+def test_slices_per_block_layouts_are_bit_identical(S, A, B, bf16, monkeypatch):
+    """Large batches run forward blocks / backward (b) blocks that walk 2 or 4 column slices (launch_fwd / launch_bwd in
+    csrc/iqlhip.hip).  The layout must not change a single bit: every layout forced through the library's diagnostic
+    switches gives the parameters, moments and losses of the one-slice layout after two steps (ragged batches too)."""
+    build, _, _, read_params, to_tb, _ = _hip()
+    from hip_helpers import read_moments
+    params = synth.synth_params(S, A, seed=71)
+    hyper = {"iql_tau": 0.8, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    lrs = {"v": 3e-4, "q": 3e-4, "pi": 3e-4}
+    d = synth.synth_transitions(B, S, A, seed=72)
+    batch = {"s": d["observations"], "a": d["actions"], "r": d["rewards"], "ns": d["next_observations"],
+             "d": d["terminals"]}
+    outs = {}
+    for fwd, bwd in (("0", "0"), ("1", "1"), ("2", "2"), (None, None)):
+        for var, val in (("IQLHIP_FWD_SPB_L2", fwd), ("IQLHIP_BWD_SPB_L2", bwd)):
+            if val is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, val)              # read when the library context is created (first step)
+        tr = build(params, S, A, True, hyper, lrs, 1000)
+        if bf16:
+            tr.set_precision("bf16")
+        logs = [tr.train(to_tb(batch)) for _ in range(2)]
+        outs[(fwd, bwd)] = (logs, read_params(tr), read_moments(tr))
+    ref = outs[("0", "0")]
+    for key, (logs, prm, mom) in outs.items():
+        assert logs == ref[0], key
+        for n in prm:
+            for k in prm[n]:
+                assert np.array_equal(prm[n][k], ref[1][n][k]), (key, n, k)
+        for which in ("m", "v"):
+            for n in mom[which]:
+                for k in mom[which][n]:
+                    assert np.array_equal(mom[which][n][k], ref[2][which][n][k]), (key, which, n, k)
+
+
 @pytest.mark.parametrize("S,A,B,gaussian", [
     (100, 28, 64, True),     # k_in = 128 (limit): layer-0 weights streamed from global, 8 k-tiles in dW0
     (96, 32, 40, False),     # action_dim = 32 (limit): two 16-wide head tiles, four pi chunks
