@@ -120,6 +120,7 @@ struct iqlhip_ctx {
   size_t lds_fwd = 0, lds_fwd_solo = 0, lds_bwd = 0;
   int n_cus = 256;                    // compute units of the device (MI355X: 256)
   int w0_lds_k = 0;                   // widest layer-0 input whose weights the forward stages in LDS
+  int bwd_donate_pct = -1;            // diagnostic (IQLHIP_BWD_DONATE_PCT): share of the policy's dW1 tiles run on the other XCDs
   int bwd_spb_force = -1;             // the same for the backward's (b) blocks (IQLHIP_BWD_SPB_L2)
   int fwd_spb_force = -1;             // diagnostic (IQLHIP_FWD_SPB_L2): fixed slices-per-block exponent of the forward
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
@@ -276,6 +277,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   else if (ks_ <= W0_DMA_MAX_K && fits(ks_)) w0_lds_k = ks_;
   if (const char* ov = getenv("IQLHIP_W0_LDS_K")) w0_lds_k = std::min(w0_lds_k, atoi(ov));   // diagnostic (tools/): force a narrower staging
   c->w0_lds_k = w0_lds_k;
+  if (const char* ov = getenv("IQLHIP_BWD_DONATE_PCT")) c->bwd_donate_pct = std::max(0, std::min(100, atoi(ov)));   // diagnostic (tools/)
   if (const char* ov = getenv("IQLHIP_BWD_SPB_L2")) c->bwd_spb_force = std::max(0, std::min(2, atoi(ov)));   // diagnostic (tools/)
   if (const char* ov = getenv("IQLHIP_FWD_SPB_L2")) c->fwd_spb_force = std::max(0, std::min(2, atoi(ov)));   // diagnostic (tools/)
   c->lds_fwd = fwd_fixed + (size_t)HID * w0_lds_k * sizeof(float) + (w0_lds_k > W0_LDS_MAX_K ? 4096 : 0);
@@ -608,9 +610,18 @@ static void launch_bwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t 
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   const int n_chunk = (p.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
   const int l2 = bwd_spb_l2(c, n_chunk, n_rt);
-  p.spb_l2 = l2 << 2;
   const int per_net = 32 * n_chunk + (4 >> l2) * n_rt;
-  const dim3 grid(8 * ((per_net + 1) / 2));
+  // multi-round launches: this many of the policy's dW1-tile blocks run at the ends of the scalar nets' XCD queues
+  // (iql_bwd_kernel); share of its 32 n_chunk tiles tuned on obs 17 / act 6 and obs 39 / act 28 (profiles/r02_slices_per_block.txt)
+  // Measured optimum of the share: 50 % at 28 action dims (1 024 rows 37.6 -> 30.8 us, bf16 32.7 -> 24.3; 2 048 rows
+  // 76.0 -> 59.1), 30 % at 6-8 action dims (1 024 rows 28.7 -> 26.5); in between: linear in the action dims.
+  int n_don = 0;
+  if (l2 > 0) {
+    const int pct = (c->bwd_donate_pct >= 0) ? c->bwd_donate_pct : std::max(30, std::min(50, 22 + c->dims.action_dim));
+    n_don = std::min(32 * n_chunk, (32 * n_chunk * pct + 50) / 100);
+  }
+  p.spb_l2 = (l2 << 2) | (n_don << 8);
+  const dim3 grid(8 * ((per_net + 1) / 2 + (n_don + 5) / 6));
   const bool full = (p.rows % CHUNK_ROWS) == 0;      // every tile of every block lies inside the batch: no clamps
   const bool bf = c->precision == 1, multi = l2 > 0;
 #define BWD_LAUNCH(BF, FU, MU) hipLaunchKernelGGL((iql_bwd_kernel<BF, FU, MU>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt)

@@ -224,8 +224,31 @@ __device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld
 // W0DMA: the variant that may stage wide layer-0 weights by LDS-DMA.  A separate instantiation because the mere
 // presence of an LDS-DMA makes the compiler wait vmcnt(0) before LDS reads on every path it may reach (measured:
 // +1 us on the narrow-input configs, whose W1 prefetch then no longer streams under layer 0).
+// Layer 0 with bf16 operands: the 8 k-steps of a chunk (lane group g holds k = 4 ks + g, ks = 0..7, of both operands)
+// are one v_mfma_f32_16x16x32_bf16 per (row tile, unit tile): 8 MFMAs of 16 cycles instead of 64 of 32.
+__device__ __forceinline__ void l0_chunk_bf16(f32x4 (&acc)[2][4], const float (&bq)[8][4], const float (&aq)[8][2]) {
+  bf16x8 B[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float t8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t8[e] = aq[e][r];
+    B[r] = pack8s(t8);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    float t8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t8[e] = bq[e][ct];
+    const bf16x8 A = pack8s(t8);
+    acc[0][ct] = MFMA_BF16(A, B[0], acc[0][ct]);
+    acc[1][ct] = MFMA_BF16(A, B[1], acc[1][ct]);
+  }
+}
+
+// (two waves per SIMD — 256 registers, accumulators included — so that two blocks can share a CU when LDS allows)
 template <bool BF16, bool W0DMA, bool MULTI>
-__global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void iql_fwd_kernel(StepParams p) {
   RT_ENTRY();
   const int bid = blockIdx.x;
   const int inst = (p.only_inst >= 0) ? p.only_inst : (bid & 7);
@@ -401,13 +424,17 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
         asm volatile("" : "+v"(aq[ks][0]), "+v"(aq[ks][1]));
       }
       STAMP(p, 5);
+      if (BF16) {       // (k-steps beyond nks: X side selected to zero above, weight side a clamped finite value)
+        l0_chunk_bf16(acc, bq, aq);
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks < nks) {
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks < nks) {
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
-            acc[0][ct] = MFMA16(bq[ks][ct], aq[ks][0], acc[0][ct]);
-            acc[1][ct] = MFMA16(bq[ks][ct], aq[ks][1], acc[1][ct]);
+            for (int ct = 0; ct < 4; ++ct) {
+              acc[0][ct] = MFMA16(bq[ks][ct], aq[ks][0], acc[0][ct]);
+              acc[1][ct] = MFMA16(bq[ks][ct], aq[ks][1], acc[1][ct]);
+            }
           }
         }
       }
@@ -438,10 +465,22 @@ __global__ __launch_bounds__(256) void iql_fwd_kernel(StepParams p) {
             }
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) asm volatile("" : "+v"(aq[4 * h + k4][0]), "+v"(aq[4 * h + k4][1]));
+          } else if (BF16) {      // the bf16 MFMA takes all 8 k-steps of a chunk: the unread half contributes zeros
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+              aq[4 * h + k4][0] = 0.f;
+              aq[4 * h + k4][1] = 0.f;
+#pragma unroll
+              for (int ct = 0; ct < 4; ++ct) bq[4 * h + k4][ct] = 0.f;
+            }
           }
         }
       };
       auto mm = [&](const float (&bq)[8][4], const float (&aq)[8][2], const int base) {
+        if (BF16) {
+          l0_chunk_bf16(acc, bq, aq);
+          return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           if (base + ks < nks) {
@@ -812,9 +851,31 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   RT_ENTRY();
   const int bid = blockIdx.x;
   const int x = bid & 7;
-  const int net = x & 3;
-  const int local_ = (bid >> 3) * 2 + (x >> 2);
+  // A net's blocks stay on two XCDs (net = x & 3: its weights and activations live in those two L2s; rotating the nets
+  // over all XCDs made multi-round launches 5-8 % SLOWER).  But the policy's blocks are 1.5-2.5x as long as the scalar
+  // nets', and in a multi-round launch XCDs 3 and 7 finished at 33 us while the other six idled from 17 us on (obs 39 /
+  // act 28, 1 024 rows, bf16).  MULTI: the policy's LAST n_don dW1-tile blocks are therefore moved to the FRONT of the
+  // other six XCDs' queues (the first ceil(n_don / 6) grid rows; host: launch_bwd) — long blocks first: at the ends of
+  // those queues they started at 22 us and finished at 36; their old slots return at once.
   const int n_a = 32 * n_chunk;
+  const int bsl2 = MULTI ? ((p.spb_l2 >> 2) & 3) : 0;     // (b) blocks: log2 of the column slices per block
+  const int n_b = (4 >> bsl2) * n_rt;
+  int net = x & 3;
+  int local_ = (bid >> 3) * 2 + (x >> 2);
+  if (MULTI) {
+    const int n_don = p.spb_l2 >> 8;
+    const int n_e = (n_don + 5) / 6;
+    const int q = bid >> 3;
+    if (q < n_e) {
+      const int j = q * 6 + (x - (x >> 2));       // x in {0,1,2,4,5,6} -> 0..5
+      if (net == IQLHIP_NET_PI || j >= n_don) return;
+      net = IQLHIP_NET_PI;
+      local_ = n_a + n_b - n_don + j;
+    } else {
+      local_ -= 2 * n_e;
+      if (net == IQLHIP_NET_PI && local_ >= n_a + n_b - n_don) return;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int B = p.rows;
@@ -841,8 +902,6 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     PIN_S(p.inv_batch); PIN_S(p.hy.iql_tau); PIN_S(p.hy.beta); PIN_S(p.hy.discount); PIN_S(p.hy.exp_adv_max);
     PIN_S(n_chunk); PIN_S(n_rt);
   }
-  const int bsl2 = MULTI ? ((p.spb_l2 >> 2) & 3) : 0;     // (b) blocks: log2 of the column slices per block
-  const int n_b = (4 >> bsl2) * n_rt;
   if (local_ >= n_a + n_b) return;
   // MULTI: the (b) blocks walk 2 / 4 slices and run 2-3x as long as a dW1 tile — they take the FIRST block indices so
   // that the launch ends on short blocks (longest first); one-slice grids keep the dW1 tiles first
@@ -1569,10 +1628,17 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           float xa[8];
 #pragma unroll
           for (int ks = 0; ks < 8; ++ks) xa[ks] = Xr[(4 * ks + g) * ld + xoff + kcc];
+          if (BF16) {      // the tile's 32 rows are ONE bf16 MFMA (lane group g holds rows 4 ks + g of both operands)
+            float a8[8];
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) {
-            const float a = (kc < k0) ? xa[ks] : ((kc == k0) ? 1.f : 0.f);   // ones column -> db0
-            acc[ct] = MFMA16(a, bv[ks], acc[ct]);
+            for (int ks = 0; ks < 8; ++ks) a8[ks] = (kc < k0) ? xa[ks] : ((kc == k0) ? 1.f : 0.f);
+            acc[ct] = MFMA_BF16(pack8s(a8), pack8s(bv), acc[ct]);
+          } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+              const float a = (kc < k0) ? xa[ks] : ((kc == k0) ? 1.f : 0.f);   // ones column -> db0
+              acc[ct] = MFMA16(a, bv[ks], acc[ct]);
+            }
           }
         }
       }

@@ -23,6 +23,8 @@ for B in BATCHES:
     tb = to_torch_batch({"s": d["observations"], "a": d["actions"], "r": d["rewards"], "ns": d["next_observations"],
                          "d": d["terminals"]})
     tr.train(tb)
+    if os.environ.get("PRECISION"):
+        tr.set_precision(os.environ["PRECISION"])
     t = [tr.time_kernel(tb, w, 300) for w in (0, 1, 2, 3)]
     n_rt, n_chunk = (B + 31) // 32, (B + 255) // 256
     print(f"S={S} A={A} B={B:4d}: fwd {t[0]:6.2f} ({7 * n_rt * 4:4d} blocks)  bwd {t[1]:6.2f} ({4 * (32 * n_chunk + 4 * n_rt):4d} blocks)  "

@@ -25,6 +25,9 @@ qf, vf, actor = iql.TwinQ(S, A).cuda(), iql.ValueFunction(S).cuda(), iql.Gaussia
 tr = iql.ImplicitQLearning(1.0, actor, torch.optim.Adam(actor.parameters(), lr=3e-4), qf,
                            torch.optim.Adam(qf.parameters(), lr=3e-4), vf, torch.optim.Adam(vf.parameters(), lr=3e-4),
                            max_steps=1000000, device="cuda")
+if os.environ.get("PRECISION"):
+    tr.train_on_buffer(buf, B, seed=7)
+    tr.set_precision(os.environ["PRECISION"])
 for it in range(50):
     tr.train_on_buffer(buf, B, seed=7)
 torch.cuda.synchronize()
@@ -91,15 +94,22 @@ def xcd_spans(name, blocks, last):
 
 
 n_rt = (B + 31) // 32
-fwd_blocks = np.arange(8 * n_rt * 4)
+fsl2 = int(os.environ.get("IQLHIP_FWD_SPB_L2", 0 if 8 * n_rt * 4 <= 256 else (1 if 8 * n_rt * 2 <= 256 else 2)))
+fwd_blocks = np.arange(8 * n_rt * (4 >> fsl2))
 report("fwd prologue", fwd_blocks, [(8, "stamp cost"), (9, "issue all loads"), (10, "wait X rows + LDS store"), (11, "wait W2/W0 + LDS stores"), (1, "barrier")])
 report("fwd", fwd_blocks, [(1, "prefetch+gather"), (5, "L0: LDS operand reads"), (6, "L0: MFMAs"), (7, "L0: epilogue + H0 writes"), (2, "L0: barrier"), (3, "H0 save + layer1"), (4, "H1 save + head")])
 n_chunk = (B + 255) // 256
-per_net = 32 * n_chunk + 4 * n_rt
+# launch_bwd's layout: beyond two rounds of the chip the (b) blocks walk 4 column slices and take the FIRST block indices
+bsl2 = int(os.environ.get("IQLHIP_BWD_SPB_L2", 2 if 4 * (32 * n_chunk + 4 * n_rt) > 512 else 0))
+n_b = (4 >> bsl2) * n_rt
+per_net = 32 * n_chunk + n_b
 nb = 8 * ((per_net + 1) // 2)
 bw = 2048 + np.arange(nb)
 ids = np.arange(nb)
 local = (ids >> 3) * 2 + ((ids & 7) >> 2)
+net_of = ids & 3
+if bsl2 > 0:         # MULTI instantiation: (b) blocks first (donated policy tiles, if any, are not tracked here)
+    local = np.where(local < n_b, 32 * n_chunk + local, local - n_b)
 a_blocks = bw[local < 32 * n_chunk]
 b_blocks = bw[(local >= 32 * n_chunk) & (local < per_net)]
 LAB_A = [(10, "issue loads"), (5, "pi: row loads + w"), (6, "pi: wS barrier"), (7, "pi: (row,dim) math"), (11, "wait heads + dY (rest)"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
@@ -108,10 +118,10 @@ LAB_B = [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red 
 if os.environ.get("PER_IT"):
     for n, nm in ((0, "V"), (3, "PI")):
         for itv in range(4):
-            report(f"bwd (a) net {nm} it=={itv}", bw[(local < 32 * n_chunk) & ((ids & 3) == n) & ((local & 3) == itv)], LAB_A)
+            report(f"bwd (a) net {nm} it=={itv}", bw[(local < 32 * n_chunk) & (net_of == n) & ((local & 3) == itv)], LAB_A)
 if os.environ.get("PER_NET"):
     for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
-        isn = (ids & 3) == n
+        isn = net_of == n
         report(f"bwd (a) net {nm}", bw[(local < 32 * n_chunk) & isn], LAB_A)
         report(f"bwd (b) net {nm}", bw[(local >= 32 * n_chunk) & (local < per_net) & isn], LAB_B)
     for i, nm in enumerate(("V(s')", "V(s)", "Qt1", "Qt2", "Q1", "Q2", "PI")):
@@ -125,9 +135,9 @@ realtime_report("bwd  (a)", a_blocks)
 realtime_report("bwd  (b)", b_blocks)
 realtime_report("bwd  all", bw)
 for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
-    realtime_report(f"bwd (b) {nm}", bw[(local >= 32 * n_chunk) & (local < per_net) & ((ids & 3) == n)])
-    realtime_report(f"bwd (a) {nm}", bw[(local < 32 * n_chunk) & ((ids & 3) == n)])
-    sel = (local < 32 * n_chunk) & ((ids & 3) == n)
+    realtime_report(f"bwd (b) {nm}", bw[(local >= 32 * n_chunk) & (local < per_net) & (net_of == n)])
+    realtime_report(f"bwd (a) {nm}", bw[(local < 32 * n_chunk) & (net_of == n)])
+    sel = (local < 32 * n_chunk) & (net_of == n)
     for itv in range(4):
         realtime_report(f"bwd (a) {nm} it=={itv}", bw[sel & ((local & 3) == itv)])
 for i, nm in enumerate(("V(s')", "V(s)", "Qt1", "Qt2", "Q1", "Q2", "PI")):
