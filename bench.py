@@ -68,7 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--action-dim", type=int, default=6)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
-                    help="f32 = the parity path (headline); bf16 = bf16 operands / fp32 accumulate in the 256-deep products")
+                    help="f32 = the parity path (headline); bf16 = bf16 operands / fp32 accumulate in the layer and weight-gradient products")
     ap.add_argument("--exchange", choices=("auto", "rccl", "p2p"), default="auto",
                     help="N > 1: gradient exchange (auto = time both in the warm-up, keep the faster valid one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -281,7 +281,7 @@ def run_rank(args, world: int) -> int:
                     if "iql_bwd_kernel" in name:
                         traffic = rec.get("hbm_bytes_per_launch_corrected")
                         mfma_util = rec.get("mfma_util")      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)
-        peak = PEAK_F32_MFMA_TFLOPS     # (bf16 mode keeps fp32 MFMAs outside the three 256-deep products; priced against fp32)
+        peak = PEAK_F32_MFMA_TFLOPS     # (bf16 mode keeps the heads and the policy's dH1 on fp32 MFMAs; priced against fp32)
         roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None if traffic is None else round(traffic),

@@ -124,8 +124,8 @@ int iqlhip_create(const iqlhip_dims* dims, const iqlhip_hyper* hyper, int device
 int iqlhip_destroy(iqlhip_ctx* ctx);
 int iqlhip_set_hyper(iqlhip_ctx* ctx, const iqlhip_hyper* hyper);
 
-/* Arithmetic of the three 256-deep matrix products (layer 1 forward, dW1, dH0): 0 = fp32 MFMA (default; the
- * parity path), 1 = operands rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16).  Master weights,
+/* Arithmetic of the large matrix products (layer 0 and layer 1 forward, dW1, dH0, dW0): 0 = fp32 MFMA (default; the
+ * parity path), 1 = operands rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16).  The heads, master weights,
  * activations in memory, losses, Adam and Polyak stay fp32.  The reference has no reduced-precision mode; this
  * is BASELINE config 5's "MFMA bf16 path" and is checked against the fp32 fixtures at 2e-2. */
 int iqlhip_set_precision(iqlhip_ctx* ctx, int mode);

@@ -105,7 +105,7 @@ struct iqlhip_ctx {
   float drop_p = 0.f;
   unsigned long long drop_seed = 0, drop_step = 0;
   bool drop_inject = false;           // tests: masks were written by iqlhip_debug_write_masks, do not regenerate
-  int precision = 0;                  // 0: fp32 MFMA everywhere; 1: bf16 operands for the 256-deep products
+  int precision = 0;                  // 0: fp32 MFMA everywhere; 1: bf16 operands for the layer-0/1, dW1, dH0, dW0 products
   float* loss_ring = nullptr;         // [ring_cap][4]
   int ring_cap = 0;
   long long* idx_chunk = nullptr;     // [GRAPH_STEPS * max_batch] row indices of the chunk in flight

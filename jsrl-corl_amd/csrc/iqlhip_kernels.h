@@ -39,7 +39,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-by
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// bf16-operand variant of the three 256-deep products (layer 1 forward, dW1, dH0): fp32 accumulate, fp32
+// bf16-operand variant of the large products (layer 0 / layer 1 forward, dW1, dH0, dW0): fp32 accumulate, fp32
 // master weights / activations in memory; operands are rounded to bf16 in registers (v_cvt_pk_bf16_f32) and
 // eight fp32 MFMAs (8 x 4 k) collapse into one v_mfma_f32_16x16x32_bf16 (32 k).  The operand lane map of the
 // bf16 instruction is "8 k per lane"; since both operands are built from the same (lane, element) -> k

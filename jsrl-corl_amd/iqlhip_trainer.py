@@ -888,8 +888,8 @@ class ImplicitQLearning:
         return float(out.value)
 
     def set_precision(self, mode: str) -> None:
-        """"f32" (default, the parity path) or "bf16": bf16 operands / fp32 accumulate for the 256-deep
-        products (BASELINE config 5's MFMA bf16 path).  Not part of the reference's surface."""
+        """"f32" (default, the parity path) or "bf16": bf16 operands / fp32 accumulate for the layer
+        and weight-gradient products (BASELINE config 5's MFMA bf16 path; heads, losses, Adam stay fp32).  Not part of the reference's surface."""
         self._require_gpu()
         if mode not in ("f32", "bf16"):
             raise ValueError("precision must be 'f32' or 'bf16'")

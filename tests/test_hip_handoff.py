@@ -200,7 +200,7 @@ def test_config5_share_fp32_and_bf16_against_reference_and_oracle():
     assert_losses(_losses(log), z["losses"], 1e-5)
     check_step_against_golden(z, meta, None, read_params(tr), read_moments(tr), param_atol=2e-6, moment_rtol=1e-5,
                               target_atol=1e-7)
-    # bf16 operands in the three 256-deep products
+    # bf16 operands in the layer / weight-gradient products
     tb16 = build(params, meta["S"], meta["A"], True, hyper, meta["lrs"], meta["max_steps"], dropout=p)
     tb16.set_precision("bf16")
     tb16.inject_dropout_masks(k0, k1)
