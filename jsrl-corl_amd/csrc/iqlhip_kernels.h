@@ -378,11 +378,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   }
   __syncthreads();
   // the W1 fragments are requested only now: 16 x 1 KB per wave of row-fragment loads take ~1.5 k cycles of the CU's
-  // one vector-memory pipe just to ISSUE — in front of the barrier they delayed layer 0 by that much; here they
-  // stream in under layer 0's 4 k cycles
-  {
+  // one vector-memory pipe (64 B/clk) just to ISSUE — in front of the barrier they delayed layer 0 by that much.  The
+  // fp32 paths with LDS-staged weights go one step further and request them BETWEEN the groups of layer-0 MFMAs (an MFMA
+  // holds the SIMD's issue for 8 of its 32 cycles: four loads per 8 MFMAs trickle out at 42 B/clk over the four waves),
+  // so that not even the issue time stands in front of layer 0.
+  const bool bw_in_l0 = !BF16 && w0_lds;
+#define BW_LOAD(ks_) bw[ks_] = *(const f32x4*)(np.w1 + (unsigned)(n1 * HID + 16 * (ks_) + 4 * g))
+  if (!bw_in_l0) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) bw[ks] = *(const f32x4*)(np.w1 + (unsigned)(n1 * HID + 16 * ks + 4 * g));
+    for (int ks = 0; ks < 16; ++ks) BW_LOAD(ks);
   }
   STAMP(p, 1);
 
@@ -435,6 +439,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
               acc[0][ct] = MFMA16(bq[ks][ct], aq[ks][0], acc[0][ct]);
               acc[1][ct] = MFMA16(bq[ks][ct], aq[ks][1], acc[1][ct]);
             }
+          }
+          if (ks < 4) {       // W1 fragments 4 ks .. 4 ks + 3 behind this group of MFMAs
+#pragma unroll
+            for (int k2 = 4 * ks; k2 < 4 * ks + 4; ++k2) BW_LOAD(k2);
           }
         }
       }
@@ -489,6 +497,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
               acc[0][ct] = MFMA16(bq[ks][ct], aq[ks][0], acc[0][ct]);
               acc[1][ct] = MFMA16(bq[ks][ct], aq[ks][1], acc[1][ct]);
             }
+          }
+          if (base == 0) {    // the W1 fragments, two behind each MFMA group of the first chunk
+            BW_LOAD(2 * ks);
+            BW_LOAD(2 * ks + 1);
           }
         }
       };
@@ -1441,9 +1453,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     }
     __syncthreads();
     STAMP(p, 5);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      bw[ks] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * ks + g) * HID + i0 + 4 * l15));
+    // (requested two at a time between the row groups of the dH1 tile below: the four waves' 64 KB take ~1 k cycles of
+    //  the CU's 64 B/clk fill path, which the tile's arithmetic covers instead of waiting behind it)
+#define BWB_LOAD(ks_) bw[ks_] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * (ks_) + g) * HID + i0 + 4 * l15))
 
     // dH1s[r][j] = (sum_dd dY[r][dd] W2[dd][j]) * (H1[r][j] > 0)
     if (D > 8) {
@@ -1483,6 +1495,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? sacc[q][e] * dscale : 0.f;
         *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+        BWB_LOAD(2 * q);
+        BWB_LOAD(2 * q + 1);
       }
     } else {
 #pragma unroll
@@ -1505,6 +1519,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
         *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+        BWB_LOAD(2 * q);
+        BWB_LOAD(2 * q + 1);
       }
     }
     __syncthreads();
