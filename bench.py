@@ -307,7 +307,7 @@ def run_rank(args, world: int) -> int:
         if probe:
             cfg["exchange_probe"] = probe
     out = {
-        "metric": "IQL gradient-steps/sec at batch=256 (D4RL obs/act dims)",
+        "metric": f"IQL gradient-steps/sec at batch={B} (D4RL obs/act dims)",      # BASELINE.json's metric at the default B = 256
         "value": round(value, 1),
         "unit": "steps/s",
         "n_gpus": world,
