@@ -200,11 +200,12 @@ def test_split_step_equals_fused_step():
             assert np.array_equal(pa[n][k], pb[n][k]), (n, k)
 
 
-@pytest.mark.parametrize("K,B", [(7, 256), (1, 100), (4, 33)])
+@pytest.mark.parametrize("K,B", [(7, 256), (1, 100), (4, 33), (5, 600), (18, 1024)])
 def test_train_steps_graph_matches_eager_steps_on_same_indices(K, B):
     """K steps replayed as one hipGraph (device index draw; the rows of step k+1 staged by the idle blocks of forward
     k into the other staging buffer) equal K eager steps fed with the same indices — bitwise.  Odd and even K, K = 1,
-    ragged batches."""
+    ragged batches; 600 and 1 024 rows run the multi-slice block layouts (fewer idle forward blocks stage the next
+    rows; 18 steps = one 16-step chunk graph + 2 direct steps)."""
     import ctypes as C
     import iql
     import iqlhip_binding as hb
