@@ -189,7 +189,13 @@ def run_rank(args, world: int) -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
+    eager_dp = [False]      # N > 1 with no in-library exchange available: one library step + torch all-reduce per step
+
     def run(n):
+        if eager_dp[0]:
+            for _ in range(n):
+                tr.train_on_buffer(buf, B, seed=1234)
+            return
         tr.train_steps(buf, n, B, seed=1234, return_losses=False)
 
     def timed(n):
@@ -222,9 +228,13 @@ def run_rank(args, world: int) -> int:
         want = args.exchange
         tr.enable_data_parallel(exchange={"auto": "both", "rccl": "rccl", "p2p": "p2p"}[want])
         modes = ["p2p", "rccl"] if want == "auto" else [want]
-        if want == "auto" and tr._dp_exchange != "p2p":      # peer mapping failed somewhere: the collective library only
-            modes = ["rccl"]
-            probe["p2p"] = {"unavailable": getattr(tr, "_p2p_error", "attach failed")}
+        if want == "auto":
+            for m, attr in (("p2p", "_p2p_error"), ("rccl", "_rccl_error")):
+                if getattr(tr, attr, None):              # that exchange could not be attached on some rank
+                    modes.remove(m)
+                    probe[m] = {"unavailable": getattr(tr, attr)}
+            if not modes:                                # (enable_data_parallel fell back to torch.distributed)
+                eager_dp[0] = True
         for m in modes:
             tr.select_exchange(m)
             tr.prepare_train_steps(buf, B)
@@ -232,7 +242,9 @@ def run_rank(args, world: int) -> int:
             # the warm-up steps are split between the two exchanges and timed; the faster one that kept the replicas
             # bit-identical runs the timed region.  (Too few warm-up steps to tell: RCCL, the vendor's collective.)
             half = warm // 2
-            if len(modes) == 1:
+            if not modes:
+                exchange = "torch"
+            elif len(modes) == 1:
                 exchange = modes[0]
             elif half >= 8:
                 for m in modes:
@@ -244,7 +256,8 @@ def run_rank(args, world: int) -> int:
                 exchange = max(ok, key=lambda m: probe[m]["steps_per_s"]) if ok else "rccl"
             else:
                 exchange = "rccl"
-            tr.select_exchange(exchange)
+            if modes:
+                tr.select_exchange(exchange)
         else:
             exchange = want
     else:

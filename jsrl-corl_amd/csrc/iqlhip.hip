@@ -729,6 +729,8 @@ extern "C" int iqlhip_p2p_export(iqlhip_ctx* c, void* handle_out, int rank, int 
     return fail(IQLHIP_EINVAL, "rank %d / world %d outside [0, %d]", rank, world, IQLHIP_MAX_WORLD);
   if (c->nccl_comm && (world != c->world || rank != c->rank))
     return fail(IQLHIP_EINVAL, "rank/world differ from the RCCL communicator");
+  if (getenv("IQLHIP_P2P_DISABLE"))     // diagnostic: lets the callers' fallback paths be exercised on any machine
+    return fail(IQLHIP_EUNSUPPORTED, "the peer-to-peer exchange is disabled (IQLHIP_P2P_DISABLE)");
   DevGuard guard(c->device);
   if (!c->xblk) {
     const size_t flags_b = 4096;                                     // IQLHIP_MAX_WORLD x 128-B flag lines, padded

@@ -686,16 +686,35 @@ class ImplicitQLearning:
         if exchange == "torch":
             self._dp_exchange = "torch"
             return
+        src = dist.get_global_rank(process_group, 0) if process_group else 0
         if exchange in ("rccl", "both"):
+            # collective-safe like the peer mapping below: a failure on any rank (no librccl, communicator init) is
+            # agreed on by all ranks before anyone relies on the collective
+            err = None
             uid = (C.c_char * hb.IQLHIP_UNIQUE_ID_BYTES)()
             if rank == 0:
-                hb.check(lib.iqlhip_comm_unique_id(uid))
-            box = [bytes(uid.raw)]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group else 0,
-                                       group=process_group)
-            ubuf = C.create_string_buffer(box[0], hb.IQLHIP_UNIQUE_ID_BYTES)
-            hb.check(lib.iqlhip_allreduce_init(self._ctx, ubuf, rank, world))
-            self._dp_exchange = "rccl"
+                try:
+                    hb.check(lib.iqlhip_comm_unique_id(uid))
+                except Exception as e:      # noqa: BLE001 - reported after the collective
+                    err = e
+            box = [None if err is not None else bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=src, group=process_group)
+            if box[0] is None:
+                err = err or RuntimeError("rank 0 could not create a communicator id")
+            else:
+                ubuf = C.create_string_buffer(box[0], hb.IQLHIP_UNIQUE_ID_BYTES)
+                try:
+                    hb.check(lib.iqlhip_allreduce_init(self._ctx, ubuf, rank, world))
+                except Exception as e:      # noqa: BLE001
+                    err = e
+            oks = [None] * world
+            dist.all_gather_object(oks, err is None, group=process_group)
+            if all(oks):
+                self._dp_exchange = "rccl"
+            else:
+                self._rccl_error = f"RCCL exchange unavailable on ranks {[i for i, o in enumerate(oks) if not o]}: {err}"
+                if exchange == "rccl":
+                    raise RuntimeError("iqlhip: " + self._rccl_error)
         if exchange in ("p2p", "both"):
             if world > hb.IQLHIP_MAX_WORLD:
                 raise ValueError(f"the p2p exchange serves one node (<= {hb.IQLHIP_MAX_WORLD} ranks), got {world}")
@@ -721,12 +740,15 @@ class ImplicitQLearning:
             if all(oks):
                 self._dp_exchange = "p2p"
             else:
+                self._p2p_error = f"p2p exchange unavailable on ranks {[i for i, o in enumerate(oks) if not o]}: {err}"
                 if self._dp_exchange == "rccl":          # "both": keep the collective library's exchange
                     hb.check(lib.iqlhip_xch_select(self._ctx, hb.XCH_RCCL))
-                    self._p2p_error = f"p2p exchange unavailable on ranks {[i for i, o in enumerate(oks) if not o]}: {err}"
-                else:
-                    raise RuntimeError(f"iqlhip: p2p exchange could not be attached on ranks "
-                                       f"{[i for i, o in enumerate(oks) if not o]}: {err}")
+                elif exchange == "p2p":
+                    raise RuntimeError("iqlhip: " + self._p2p_error)
+        if exchange == "both" and self._dp_exchange not in ("rccl", "p2p"):
+            # neither in-library exchange came up: the eager torch.distributed exchange still trains correctly
+            # (train() / train_on_buffer(); train_steps needs an in-library exchange)
+            self._dp_exchange = "torch"
 
     def select_exchange(self, exchange: str) -> None:
         """Switch between attached in-library exchanges ("rccl" / "p2p"); collective: every rank must do the same."""
