@@ -559,6 +559,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   // right after this slice's layer-1 MFMAs and arrive under its head phase.
   for (int it = 0;; ++it) {
   const bool more = MULTI && (it + 1 < spb);
+  f32x4 bias1n = bias1;
+  if (more) {      // the next slice's head weights and bias: requested a whole layer 1 ahead of their LDS store at the
+                   // end of this pass (requested after the layer they waited ~1 k cycles in front of that store)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = min(tid + 256 * q, D * 16 - 1);
+      w2pre[q] = *(const f32x4*)(np.w2 + (unsigned)((e >> 4) * HID + (ns + 1) * 64 + 4 * (e & 15)));
+    }
+    bias1n = *(const f32x4*)(np.b1 + (unsigned)((ns + 1) * 64 + wave * 16 + 4 * g));
+  }
   // save H0 columns [64*ns, +64) of the trainable instances for the backward pass
   if (slot >= 0) {
     float* dst = h0g + slot * MB * HID;
@@ -631,16 +641,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   }
   __syncthreads();
   STAMP(p, 3);
-  f32x4 bias1n = bias1;
-  if (more) {      // the next slice's head weights and bias
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = min(tid + 256 * q, D * 16 - 1);
-      w2pre[q] = *(const f32x4*)(np.w2 + (unsigned)((e >> 4) * HID + (ns + 1) * 64 + 4 * (e & 15)));
-    }
-    bias1n = *(const f32x4*)(np.b1 + (unsigned)((ns + 1) * 64 + wave * 16 + 4 * g));
-    n1 += 64;
-  }
+  if (more) n1 += 64;
 
   {
     const int rl = tid >> 3;
