@@ -1755,8 +1755,27 @@ __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
   return n;
 }
 
+// The layout words of a lane's net, WITHOUT indexing the kernel-argument block by the lane's net: `u.L.net[net]` with a
+// per-lane index is a vector load from the argument block — a memory round trip that the gradient loads then wait for
+// (they need these words for their address), i.e. a second dependent round trip in a kernel that otherwise has one.
+// All four nets' words are uniform scalar loads; the lane selects.
+struct NetWords { long long w0, b0; int k_in; long long slab_b_off; };
+__device__ __forceinline__ NetWords net_words(const UpdParams& u, int net) {
+  NetWords r;
+  r.w0 = u.L.net[0].w0; r.b0 = u.L.net[0].b0; r.k_in = u.L.net[0].k_in; r.slab_b_off = u.slab_b_off[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    const bool is = (net == i);
+    r.w0 = is ? u.L.net[i].w0 : r.w0;
+    r.b0 = is ? u.L.net[i].b0 : r.b0;
+    r.k_in = is ? u.L.net[i].k_in : r.k_in;
+    r.slab_b_off = is ? u.slab_b_off[i] : r.slab_b_off;
+  }
+  return r;
+}
+
 __device__ __forceinline__ f32x4 slab_grad(const UpdParams& u, long long e, int net) {
-  const iqlhip_net_layout& nl = u.L.net[net];
+  const NetWords nl = net_words(u, net);
   f32x4 gsum = (f32x4){0.f, 0.f, 0.f, 0.f};
   // slabs are read 8 at a time with unconditional (clamped) loads: a load inside a runtime-count loop
   // would be waited for individually — one dependent round trip per slab.
@@ -1765,7 +1784,7 @@ __device__ __forceinline__ f32x4 slab_grad(const UpdParams& u, long long e, int 
   int n;
   if (e >= nl.w0 && e < nl.b0 + HID) {
     stride = (long long)HID * nl.k_in + HID;
-    base = u.slab_b + u.slab_b_off[net] + (e - nl.w0);
+    base = u.slab_b + nl.slab_b_off + (e - nl.w0);
     n = u.n_rt;
   } else {
     stride = u.L.n_params;
@@ -1960,6 +1979,20 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
                    u.d_hdr[HDR_DROP_STEP] + (unsigned long long)u.d_k, mb * 256 + threadIdx.x, nmb * 256);
     return;
   }
+  // every kernel-argument word the optimizer path uses, fetched in ONE batch of scalar loads (hipcc otherwise sinks
+  // each load next to its first use: five dependent scalar-cache misses in front of the gradient loads).  ONE asm
+  // statement for all of them: a volatile asm per word is ordered against the others and gets its own wait.
+#define U64(x) ((unsigned long long)(x))
+  asm volatile("" ::"s"(U64(u.L.net[0].seg_begin)), "s"(U64(u.L.net[1].seg_begin)), "s"(U64(u.L.net[2].seg_begin)),
+               "s"(U64(u.L.net[3].seg_begin)), "s"(U64(u.L.net[0].w0)), "s"(U64(u.L.net[1].w0)), "s"(U64(u.L.net[2].w0)),
+               "s"(U64(u.L.net[3].w0)), "s"(U64(u.L.net[0].b0)), "s"(U64(u.L.net[1].b0)), "s"(U64(u.L.net[2].b0)),
+               "s"(U64(u.L.net[3].b0)), "s"(u.L.net[0].k_in), "s"(u.L.net[1].k_in), "s"(u.L.net[2].k_in),
+               "s"(u.L.net[3].k_in), "s"(U64(u.slab_b_off[0])), "s"(U64(u.slab_b_off[1])), "s"(U64(u.slab_b_off[2])),
+               "s"(U64(u.slab_b_off[3])), "s"(U64(u.L.n_params)), "s"(U64(u.L.target_src)), "s"(U64((uintptr_t)u.params)),
+               "s"(U64((uintptr_t)u.target)), "s"(U64((uintptr_t)u.m)), "s"(U64((uintptr_t)u.v)),
+               "s"(U64((uintptr_t)u.slab_a)), "s"(U64((uintptr_t)u.slab_b)), "s"(U64((uintptr_t)u.flat_grads)),
+               "s"(U64((uintptr_t)u.sched)));
+#undef U64
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (e < u.L.n_params) {
     const int net = net_of(u.L, e);
@@ -1975,12 +2008,12 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     if (PEER) {
       // all ranks' contributions requested together (one fabric round trip), summed in rank order
       static_assert(IQLHIP_MAX_WORLD == 8, "load16_sys_x8");
-      const iqlhip_net_layout& nl = u.L.net[net];
+      const NetWords nl = net_words(u, net);
       if (u.peer_direct && e >= nl.w0 && e < nl.b0 + HID) {
         // w0 / b0: every rank's <= 8 row-tile partial slabs, summed per rank in slab order (exactly slab_grad's sum,
         // i.e. what that rank's flatten kernel would have written), then over the ranks in rank order
         const long long stride = (long long)HID * nl.k_in + HID;
-        const long long off = u.slab_b_off[net] + (e - nl.w0);
+        const long long off = nl.slab_b_off + (e - nl.w0);
         gr = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < u.n_peer; ++r) {
           f32x4 pv[8];
@@ -2017,18 +2050,20 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     const float omb1 = sc.one_minus_beta1, b2 = sc.beta2, omb2 = sc.one_minus_beta2, eps = sc.eps;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      // (the fused multiply-adds are spelled out: left to -ffp-contract the four instantiations of this kernel are free
+      //  to fuse differently, and the exchange variants must stay bitwise equal to the plain one)
       const float gk = (gs == 1.f) ? gr[k] : gr[k] * gs;
-      m[k] = m[k] + omb1 * (gk - m[k]);
-      v[k] = v[k] * b2 + (omb2 * gk) * gk;
+      m[k] = fmaf(omb1, gk - m[k], m[k]);
+      v[k] = fmaf(omb2 * gk, gk, v[k] * b2);
       const float denom = sqrtf(v[k]) / bc2 + eps;
-      pw[k] = pw[k] + step * (m[k] / denom);
+      pw[k] = fmaf(step, m[k] / denom, pw[k]);
     }
     *(f32x4*)(u.m + e) = m;
     *(f32x4*)(u.v + e) = v;
     *(f32x4*)(u.params + e) = pw;
     if (is_q) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) t[k] = u.one_minus_tau * t[k] + u.tau * pw[k];
+      for (int k = 0; k < 4; ++k) t[k] = fmaf(u.tau, pw[k], u.one_minus_tau * t[k]);
       *(f32x4*)tp = t;
     }
   }
