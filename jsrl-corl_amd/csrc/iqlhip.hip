@@ -294,6 +294,9 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
                                 RT_ROWS * XR_LD_MAX) * sizeof(float);
   c->lds_bwd = std::max(lds_a, lds_b);
   {
+    const void* fwd1[4] = {(const void*)iql_fwd_kernel<false, false, false, true>, (const void*)iql_fwd_kernel<false, true, false, true>,
+                           (const void*)iql_fwd_kernel<true, false, false, true>,  (const void*)iql_fwd_kernel<true, true, false, true>};
+    for (const void* f : fwd1) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_fwd_solo));
     const void* fwd[8] = {(const void*)iql_fwd_kernel<false, false, false>, (const void*)iql_fwd_kernel<false, true, false>,
                           (const void*)iql_fwd_kernel<true, false, false>,  (const void*)iql_fwd_kernel<true, true, false>,
                           (const void*)iql_fwd_kernel<false, false, true>,  (const void*)iql_fwd_kernel<false, true, true>,
@@ -569,7 +572,11 @@ static void launch_fwd_grid(const iqlhip_ctx* c, const StepParams& p, int nb, hi
   const size_t lds = fwd_lds(c, nb);
   const bool bf = c->precision == 1, multi = (p.spb_l2 & 3) > 0;
 #define FWD_LAUNCH(BF, DMA, MU) hipLaunchKernelGGL((iql_fwd_kernel<BF, DMA, MU>), dim3(nb), dim3(256), lds, st, p)
-  if (multi) {
+#define FWD_LAUNCH_ONE(BF, DMA) hipLaunchKernelGGL((iql_fwd_kernel<BF, DMA, false, true>), dim3(nb), dim3(256), lds, st, p)
+  if (p.only_inst >= 0) {        // policy inference (iqlhip_actor_forward): its own instantiation
+    if (bf) { if (dma) FWD_LAUNCH_ONE(true, true); else FWD_LAUNCH_ONE(true, false); }
+    else    { if (dma) FWD_LAUNCH_ONE(false, true); else FWD_LAUNCH_ONE(false, false); }
+  } else if (multi) {
     if (bf) { if (dma) FWD_LAUNCH(true, true, true); else FWD_LAUNCH(true, false, true); }
     else    { if (dma) FWD_LAUNCH(false, true, true); else FWD_LAUNCH(false, false, true); }
   } else {
@@ -577,6 +584,7 @@ static void launch_fwd_grid(const iqlhip_ctx* c, const StepParams& p, int nb, hi
     else    { if (dma) FWD_LAUNCH(false, true, false); else FWD_LAUNCH(false, false, false); }
   }
 #undef FWD_LAUNCH
+#undef FWD_LAUNCH_ONE
 }
 
 // Column slices per forward block (log2).  One block per (instance, row tile, slice) while that grid fits the chip in

@@ -247,12 +247,15 @@ __device__ __forceinline__ void l0_chunk_bf16(f32x4 (&acc)[2][4], const float (&
 }
 
 // (two waves per SIMD — 256 registers, accumulators included — so that two blocks can share a CU when LDS allows)
-template <bool BF16, bool W0DMA, bool MULTI>
+// ONE: the policy-inference launch (one instance, p.only_inst).  A template flag rather than a run-time test of
+// p.only_inst: the test was a scalar load + wait + branch in FRONT of the argument batch below — two dependent
+// scalar-cache misses at the start of every training forward instead of one.
+template <bool BF16, bool W0DMA, bool MULTI, bool ONE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void iql_fwd_kernel(StepParams p) {
   RT_ENTRY();
   const int bid = blockIdx.x;
-  const int inst = (p.only_inst >= 0) ? p.only_inst : (bid & 7);
-  const int rest = (p.only_inst >= 0) ? bid : (bid >> 3);
+  const int inst = ONE ? p.only_inst : (bid & 7);
+  const int rest = ONE ? bid : (bid >> 3);
   if (inst >= 7) {     // the idle eighth of the grid stages the NEXT step's rows (graph chunks), else exits
     if (p.g_idx) gather_rows_flat(p.g_rows, p.g_ld, p.g_idx, p.g_xb, p.g_n, rest * 256 + (int)threadIdx.x, (int)(gridDim.x >> 3) * 256);
     return;
