@@ -658,13 +658,15 @@ static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
   int nb = u.n_upd_blocks;
   if (u.d_bits) nb += (u.d_n_words + 255) / 256;                               // next step's dropout keep-bits
   const bool peer = u.n_peer > 0;
-  if (u.sched) {
-    if (peer) hipLaunchKernelGGL((iql_update_kernel<true, true>), dim3(nb), dim3(256), 0, st, u);
-    else hipLaunchKernelGGL((iql_update_kernel<true, false>), dim3(nb), dim3(256), 0, st, u);
+#define UPD_LAUNCH(T, P, M) hipLaunchKernelGGL((iql_update_kernel<T, P, M>), dim3(nb), dim3(256), 0, st, u)
+  if (u.d_bits) {       // the instantiations that look at their block index first (extra mask blocks)
+    if (u.sched) { if (peer) UPD_LAUNCH(true, true, true); else UPD_LAUNCH(true, false, true); }
+    else         { if (peer) UPD_LAUNCH(false, true, true); else UPD_LAUNCH(false, false, true); }
   } else {
-    if (peer) hipLaunchKernelGGL((iql_update_kernel<false, true>), dim3(nb), dim3(256), 0, st, u);
-    else hipLaunchKernelGGL((iql_update_kernel<false, false>), dim3(nb), dim3(256), 0, st, u);
+    if (u.sched) { if (peer) UPD_LAUNCH(true, true, false); else UPD_LAUNCH(true, false, false); }
+    else         { if (peer) UPD_LAUNCH(false, true, false); else UPD_LAUNCH(false, false, false); }
   }
+#undef UPD_LAUNCH
 }
 
 static void launch_flatten(const iqlhip_ctx* c, const UpdParams& u, float* out, bool sys, hipStream_t st) {

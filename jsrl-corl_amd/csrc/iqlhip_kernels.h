@@ -1971,9 +1971,11 @@ __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, floa
 // arguments are frozen, the table is not); otherwise from the kernel argument u.sc.  Two instantiations
 // rather than a run-time pointer select, which would turn every access into a flat load.
 // PEER: the direct-read exchange variant (gradient = rank-ordered sum over UpdParams::peer_flat).
-template <bool FROM_TABLE, bool PEER>
+// MASKS: the grid carries extra blocks for the next step's dropout keep-bits.  A template flag: as a run-time test it
+// was a scalar load + wait + branch in front of the argument batch in EVERY launch (cf. the forward's ONE flag).
+template <bool FROM_TABLE, bool PEER, bool MASKS = false>
 __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
-  if ((int)blockIdx.x >= u.n_upd_blocks) {
+  if (MASKS && (int)blockIdx.x >= u.n_upd_blocks) {
     // extra blocks: the next step's dropout keep-bits while the optimizer blocks run (the next step's ROWS are
     // staged by the forward kernel's idle blocks, see StepParams::g_idx)
     const int mb = (int)blockIdx.x - u.n_upd_blocks;
