@@ -1336,7 +1336,12 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       }
     }
     if (extras) {
-      for (int e = tid; e < (1 + D) * 32; e += 256) {
+      // (only the rows this block stores: row 0 = db1 costs 16 LDS reads per value, and a wave that holds row-0 AND row-1
+      //  lanes runs both paths one after the other — 790 cycles at the end of the policy's dW2 blocks, the kernel's last
+      //  blocks, which do not even own db1)
+      const int e_lo = do_db1 ? 0 : 32;
+      const int e_hi = do_dw2 ? (1 + D) * 32 : 32;
+      for (int e = tid + e_lo; e < e_hi; e += 256) {
         const int rr = e >> 5, jj = e & 31;
         float s;
         if (rr == 0 || D == 1) {
