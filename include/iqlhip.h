@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IQLHIP_VERSION 200          /* 0.2.0 */
+#define IQLHIP_VERSION 300          /* 0.3.0 */
 #define IQLHIP_HIDDEN 256           /* hidden width the kernels are tiled for (reference default, iql.py:352) */
 #define IQLHIP_MAX_INPUT 128        /* max state_dim + action_dim */
 #define IQLHIP_MAX_ACTION 32        /* max action_dim */
@@ -174,20 +174,26 @@ int iqlhip_forward_backward(iqlhip_ctx* ctx, const iqlhip_batch* batch, const iq
 int iqlhip_apply_update(iqlhip_ctx* ctx, const float* grads_dev, const iqlhip_step_scalars* sc, void* stream);
 int64_t iqlhip_grad_words(const iqlhip_ctx* ctx);   /* n_params + 4 */
 
-/* K consecutive steps captured in one hipGraph: indices are drawn on the device
- * (Philox4x32-10, uniform with replacement over [0,size) like np.random.randint
- * at iql.py:172), per-step scalars come from `sc` (host array of n_steps).
- * Loss of every step is kept in a device ring read by iqlhip_read_loss_ring.
- * Replaces the offline loop body sample()->train() (algorithms/offline/iql.py:631-635). */
+/* n_steps consecutive `sample -> train` iterations without host round trips: row indices are drawn on the device
+ * (Philox4x32-10, uniform with replacement over [0,size) like np.random.randint at iql.py:172; index j of the call comes
+ * from counter stream_offset + j / 2), per-step scalars come from `sc` (host array of n_steps, free again on return).
+ * The loss of every step is kept in a device ring read by iqlhip_read_loss_ring.
+ * Replaces the offline loop body sample()->train() (algorithms/offline/iql.py:631-635).
+ * A call = one set-up launch + replays of fixed chunk graphs (IQLHIP_GRAPH_STEPS = 64 steps, 16, 4, 2, 1) that chain on
+ * the device; nothing is captured per value of n_steps.
+ * flags: IQLHIP_TS_CONTINUE — the caller states that the replay rows have not been written since the previous
+ * iqlhip_train_steps call; if that call ended where this one starts (same rows / size / batch_rows / seed,
+ * stream_offset = its offset + n_steps * batch_rows / 2, an even n_steps, no other step entry point in between — the
+ * library checks all of that) the rows its last forward staged for "the next step" ARE this call's step 0 and nothing
+ * is gathered up front.  Results are identical with and without the flag. */
+#define IQLHIP_TS_CONTINUE 1
 int iqlhip_train_steps(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int64_t size, int32_t batch_rows,
                        const iqlhip_step_scalars* sc, int32_t n_steps, uint64_t seed, uint64_t stream_offset,
-                       void* stream);
+                       int32_t flags, void* stream);
 
-/* Capture, instantiate and upload the hipGraph chunk iqlhip_train_steps replays for this (buffer, batch_rows,
- * inv_batch) — and, with an exchange attached, this exchange mode — WITHOUT running a step, so that no later
- * iqlhip_train_steps call pays for it (bench.py calls it before its timed region).  iqlhip_train_steps composes a run
- * of n steps from replays of two fixed chunk graphs (IQLHIP_GRAPH_STEPS = 64 steps, then 16 steps) and fewer than 16
- * steps launched directly, so its cost per step does not depend on n and nothing is ever captured per value of n. */
+/* Capture, instantiate, upload AND rehearse (arenas saved and restored) every chunk graph iqlhip_train_steps replays for
+ * this (buffer, batch_rows, inv_batch) — and, with an exchange attached, this exchange mode — so that no later
+ * iqlhip_train_steps call pays for a capture or a first replay (bench.py calls it before its timed region). */
 int iqlhip_train_steps_prepare(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int32_t batch_rows, float inv_batch);
 
 /* ---- data-parallel gradient exchange (the reference has no multi-device code) ----------------
@@ -294,6 +300,9 @@ int iqlhip_debug_read(iqlhip_ctx* ctx, const char* name, float* host_out, int64_
  * 2 update with zero step size, 3 all three); average microseconds per launch.  Synchronous. */
 int iqlhip_debug_time_kernel(iqlhip_ctx* ctx, const iqlhip_batch* batch, int which, int repeat, float* avg_us,
                              void* stream);
+/* Diagnostic: queue a flag kernel on `stream` and spin on its host-mapped word (no synchronise call): microseconds
+ * until the host sees the stream drained. */
+int iqlhip_debug_drain_spin(iqlhip_ctx* ctx, void* stream, double* spin_us);
 /* Average device time (microseconds) of the kernels of the last iqlhip_step /
  * train_steps call measured with hipEvents on `stream`; 0 when timing is off. */
 int iqlhip_set_timing(iqlhip_ctx* ctx, int enabled);

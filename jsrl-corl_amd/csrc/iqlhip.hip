@@ -4,6 +4,8 @@
 
 #include <dlfcn.h>
 
+#include <time.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -13,7 +15,9 @@
 #include <vector>
 
 #define GRAPH_STEPS IQLHIP_GRAPH_STEPS
-#define GRAPH_STEPS_SMALL 16     // second captured chunk size: the tail of a call runs 16 steps at a time in-graph too
+// Captured chunk sizes: a call of n steps is composed of replays of these (every step runs inside a graph).  The even
+// sizes start and end on staging buffer 0, so they chain in any order; the one-step chunk only ever ends a call.
+static const int kChunkSizes[] = {GRAPH_STEPS, 16, 4, 2, 1};
 
 static thread_local std::string g_err;
 
@@ -35,6 +39,14 @@ static int fail(int code, const char* fmt, ...) {
 
 static inline int64_t up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Diagnostic (IQLHIP_TRACE=1): host timestamps inside iqlhip_train_steps, printed to stderr at the end of the call.
+static inline double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+static const bool g_trace = getenv("IQLHIP_TRACE") != nullptr;
+
 // Make the context's GPU the current HIP device for the duration of an entry point and restore the caller's
 // afterwards (a trainer on cuda:1 may be driven while cuda:0 is current; the library must not change that).
 struct DevGuard {
@@ -47,21 +59,22 @@ struct DevGuard {
 };
 
 // What a captured chunk graph depends on through frozen kernel arguments.  The number of steps of a call is NOT part
-// of it: a call is composed of replays of the 64-step chunk graph, then of the 16-step one, plus < 16 directly
-// launched steps (kernel boundaries inside a graph are ~0.5 us shorter than between directly launched kernels).
+// of it: a call is composed of replays of the fixed chunk graphs (64, 16, 4, 2 steps and one), nothing is ever
+// captured per call length (kernel boundaries inside a graph are ~0.5 us shorter than between directly launched kernels).
 struct GraphKey {
   const float* rows = nullptr;
   int64_t ld = 0;
   int32_t B = 0;
-  int32_t K = 0;      // steps in the chunk: GRAPH_STEPS or GRAPH_STEPS_SMALL, never the caller's step count
+  int32_t K = 0;      // steps in the chunk: one of kChunkSizes, never the caller's step count
   float* params = nullptr;
   float drop_p = 0.f;
   float inv_batch = 0.f;
   int xch = 0;        // exchange mode the chunk was captured with
   int parity = 0;     // P2P exchange: which flat buffer step 0 of the chunk writes
+  int head = 0;       // the chunk a call starts with: its graph begins with the call's set-up kernel (arguments set per replay)
   bool operator==(const GraphKey& o) const {
     return rows == o.rows && ld == o.ld && B == o.B && K == o.K && params == o.params && drop_p == o.drop_p &&
-           inv_batch == o.inv_batch && xch == o.xch && parity == o.parity;
+           inv_batch == o.inv_batch && xch == o.xch && parity == o.parity && head == o.head;
   }
 };
 
@@ -101,17 +114,24 @@ struct iqlhip_ctx {
   unsigned long long act_calls = 0;   // Philox call counter of iqlhip_actor_sample
   int64_t row_ld = 0;
   // actor dropout
-  unsigned* drop_bits = nullptr;      // [2][max_batch][8] keep-bits
+  unsigned* drop_bits = nullptr;      // [2 parities][2 layers][max_batch][8] keep-bits (a step reads one parity while the
+                                      // forward's idle blocks draw the next step's into the other)
   float drop_p = 0.f;
   unsigned long long drop_seed = 0, drop_step = 0;
   bool drop_inject = false;           // tests: masks were written by iqlhip_debug_write_masks, do not regenerate
   int precision = 0;                  // 0: fp32 MFMA everywhere; 1: bf16 operands for the layer-0/1, dW1, dH0, dW0 products
   float* loss_ring = nullptr;         // [ring_cap][4]
   int ring_cap = 0;
-  long long* idx_chunk = nullptr;     // [GRAPH_STEPS * max_batch] row indices of the chunk in flight
   iqlhip_step_scalars* sched_cur = nullptr;   // [GRAPH_STEPS] device: per-step scalars of the chunk in flight
+  iqlhip_step_scalars* sched_call = nullptr;  // [k_max] device copy of the scalar table of the call in flight
   iqlhip_step_scalars* sched_pin[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned, host-mapped copies of a call's table [k_max]
-  hipEvent_t sched_done[4] = {nullptr, nullptr, nullptr, nullptr};           // slot free again once this event has passed
+  // a slot is free again once the set-up kernel that read it has acknowledged the call's number in sched_ack[slot]
+  // (a pinned, host-mapped word the kernel writes; the host only reads memory — no event, no HIP call)
+  unsigned long long* sched_ack = nullptr;      // pinned [4]
+  unsigned long long sched_want[4] = {0, 0, 0, 0};
+  unsigned long long call_seq = 0;
+  unsigned* setup_arrivals = nullptr;           // device: block counter of iql_call_setup_kernel
+  hipStream_t sched_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // (the stream a slot's reader was queued on)
   int sched_slot = 0;
   unsigned long long* hdr = nullptr;  // [HDR_WORDS] per-launch values of a chunk (ChunkHdr)
   unsigned long long* stamps = nullptr;  // diagnostic builds (-DIQL_STAMPS): [4096 blocks][16]
@@ -125,7 +145,14 @@ struct iqlhip_ctx {
   int fwd_spb_force = -1;             // diagnostic (IQLHIP_FWD_SPB_L2): fixed slices-per-block exponent of the forward
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
   hipStream_t cap_stream = nullptr;
-  struct CachedGraph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; hipStream_t last; };
+  struct CachedGraph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; hipStream_t last;
+                       IdleWork* work; /* [K] device records of the chunk's idle-block work */
+                       hipGraphNode_t setup_node; /* head chunks: the set-up kernel's node */ };
+  // Continuation of the index stream across calls: the last forward of a call stages the rows (and keep-bits) of the
+  // step that would come next; a following call that IS that step (same rows / size / batch / seed, counter position
+  // where the previous call stopped, staging untouched in between) starts without gathering anything.
+  struct { bool valid = false; const float* rows = nullptr; int64_t ld = 0, size = 0; int32_t B = 0; uint64_t seed = 0;
+           uint64_t next_offset = 0; float drop_p = 0.f; uint64_t drop_seed = 0, drop_step = 0; } cont;
   std::vector<CachedGraph> graphs;
   unsigned long long graph_clock = 0;
   // data-parallel gradient exchange
@@ -232,8 +259,8 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   c->act_cap = std::max(MB, IQLHIP_ACT_ROWS);
   HIPCHK(dalloc(&c->xb_act, (size_t)c->act_cap * c->row_ld));
   HIPCHK(dalloc(&c->heads_act, (size_t)c->act_cap * A * NSPLIT));
-  HIPCHK(hipMalloc((void**)&c->drop_bits, (size_t)2 * MB * 8 * sizeof(unsigned)));
-  HIPCHK(hipMemset(c->drop_bits, 0xFF, (size_t)2 * MB * 8 * sizeof(unsigned)));
+  HIPCHK(hipMalloc((void**)&c->drop_bits, (size_t)4 * MB * 8 * sizeof(unsigned)));
+  HIPCHK(hipMemset(c->drop_bits, 0xFF, (size_t)4 * MB * 8 * sizeof(unsigned)));
   HIPCHK(dalloc(&c->sc.slab_a, (size_t)c->n_chunk_max * c->L.n_params));
   size_t sb = 0;
   for (int n = 0; n < 4; ++n) {
@@ -247,12 +274,15 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   c->k_max = 1024;
   c->ring_cap = c->k_max;
   HIPCHK(dalloc(&c->loss_ring, (size_t)c->ring_cap * 4));
-  HIPCHK(hipMalloc((void**)&c->idx_chunk, (size_t)GRAPH_STEPS * MB * sizeof(long long)));
   HIPCHK(hipMalloc((void**)&c->sched_cur, (size_t)GRAPH_STEPS * sizeof(iqlhip_step_scalars)));
+  HIPCHK(hipMalloc((void**)&c->sched_call, (size_t)c->k_max * sizeof(iqlhip_step_scalars)));
   for (int i = 0; i < 4; ++i) {
     HIPCHK(hipHostMalloc((void**)&c->sched_pin[i], (size_t)c->k_max * sizeof(iqlhip_step_scalars), hipHostMallocDefault));
-    HIPCHK(hipEventCreateWithFlags(&c->sched_done[i], hipEventDisableTiming));
   }
+  HIPCHK(hipHostMalloc((void**)&c->sched_ack, 8 * sizeof(unsigned long long), hipHostMallocDefault));   // [4] slots + a dummy word
+  memset(c->sched_ack, 0, 8 * sizeof(unsigned long long));
+  HIPCHK(hipMalloc((void**)&c->setup_arrivals, 64));
+  HIPCHK(hipMemset(c->setup_arrivals, 0, 64));
   HIPCHK(hipMalloc((void**)&c->hdr, HDR_WORDS * sizeof(unsigned long long)));
   HIPCHK(hipMemset(c->hdr, 0, HDR_WORDS * sizeof(unsigned long long)));
   HIPCHK(hipMalloc((void**)&c->xstatus, 2 * sizeof(unsigned long long)));
@@ -338,8 +368,10 @@ static void drop_graph(iqlhip_ctx* c) {
     if (g.last) (void)hipStreamSynchronize(g.last);   // a replay may still be executing
     (void)hipGraphExecDestroy(g.exec);
     (void)hipGraphDestroy(g.graph);
+    if (g.work) (void)hipFree(g.work);
   }
   c->graphs.clear();
+  c->cont.valid = false;
 }
 
 extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
@@ -351,13 +383,14 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
-                  c->flat_tmp, c->loss_ring, c->idx_chunk, c->sched_cur, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act,
+                  c->flat_tmp, c->loss_ring, c->sched_call, c->sched_cur, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act,
                   c->heads_act, c->drop_bits, c->xstatus, c->xflat};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < 4; ++i) {
     if (c->sched_pin[i]) (void)hipHostFree(c->sched_pin[i]);
-    if (c->sched_done[i]) (void)hipEventDestroy(c->sched_done[i]);
   }
+  if (c->sched_ack) (void)hipHostFree(c->sched_ack);
+  if (c->setup_arrivals) (void)hipFree(c->setup_arrivals);
   if (c->losses_host) (void)hipHostFree(c->losses_host);
   if (c->on_row_pin) (void)hipHostFree(c->on_row_pin);
   if (c->on_idx_pin) (void)hipHostFree(c->on_idx_pin);
@@ -416,6 +449,7 @@ extern "C" int iqlhip_debug_write_masks(iqlhip_ctx* c, const uint32_t* keep0, co
   HIPCHK(hipMemcpyAsync(c->drop_bits + (size_t)c->dims.max_batch * 8, keep1, nb, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   c->drop_inject = true;
+  c->cont.valid = false;
   return IQLHIP_OK;
 }
 
@@ -532,7 +566,7 @@ static StepParams make_step(const iqlhip_ctx* c, int rows, float inv_batch) {
   p.drop_scale = (c->drop_p > 0.f) ? 1.f / (1.f - c->drop_p) : 1.f;
   p.only_inst = -1;
   p.w0_lds_k = c->w0_lds_k;
-  p.g_rows = nullptr; p.g_ld = c->row_ld; p.g_idx = nullptr; p.g_xb = nullptr; p.g_n = 0;
+  p.g_work = nullptr;
   return p;
 }
 
@@ -556,9 +590,8 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.batch_rows = rows;
   u.sched = nullptr;
   u.sched_idx = 0;
-  u.n_upd_blocks = (int)((c->L.n_params / 4 + 255) / 256);
-  u.d_bits = nullptr; u.d_n_words = 2 * c->dims.max_batch * 8; u.d_thresh = 0; u.d_hdr = c->hdr; u.d_k = 0;
   u.ring_hdr = nullptr;
+  u.adv_hdr = nullptr; u.adv_k = 0; u.adv_rows = 0;
   u.n_peer = 0;
   u.peer_direct = 0;
   for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) { u.peer_flat[r] = nullptr; u.peer_slab_b[r] = nullptr; u.peer_loss[r] = nullptr; }
@@ -655,17 +688,11 @@ static void launch_dropmask(const iqlhip_ctx* c, unsigned long long seed, unsign
 }
 
 static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
-  int nb = u.n_upd_blocks;
-  if (u.d_bits) nb += (u.d_n_words + 255) / 256;                               // next step's dropout keep-bits
+  const int nb = (int)((c->L.n_params / 4 + 255) / 256);
   const bool peer = u.n_peer > 0;
-#define UPD_LAUNCH(T, P, M) hipLaunchKernelGGL((iql_update_kernel<T, P, M>), dim3(nb), dim3(256), 0, st, u)
-  if (u.d_bits) {       // the instantiations that look at their block index first (extra mask blocks)
-    if (u.sched) { if (peer) UPD_LAUNCH(true, true, true); else UPD_LAUNCH(true, false, true); }
-    else         { if (peer) UPD_LAUNCH(false, true, true); else UPD_LAUNCH(false, false, true); }
-  } else {
-    if (u.sched) { if (peer) UPD_LAUNCH(true, true, false); else UPD_LAUNCH(true, false, false); }
-    else         { if (peer) UPD_LAUNCH(false, true, false); else UPD_LAUNCH(false, false, false); }
-  }
+#define UPD_LAUNCH(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P>), dim3(nb), dim3(256), 0, st, u)
+  if (u.sched) { if (peer) UPD_LAUNCH(true, true); else UPD_LAUNCH(true, false); }
+  else         { if (peer) UPD_LAUNCH(false, true); else UPD_LAUNCH(false, false); }
 #undef UPD_LAUNCH
 }
 
@@ -947,6 +974,7 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   if (rc) return rc;
   DevGuard guard(c->device);
   hipStream_t st = (hipStream_t)stream;
+  c->cont.valid = false;                 // (the staging buffers / keep-bits a following train_steps call might continue from)
   const float* xb_cur = nullptr;
   rc = stage_batch(c, b, st, &xb_cur);
   if (rc) return rc;
@@ -992,6 +1020,7 @@ extern "C" int iqlhip_online_step(iqlhip_ctx* c, float* rows_dev, int64_t ld, in
     if (idx_host[i] < 0 || idx_host[i] >= capacity) return fail(IQLHIP_EINVAL, "sampled index %lld outside the buffer", (long long)idx_host[i]);
   DevGuard guard(c->device);
   hipStream_t st = (hipStream_t)stream;
+  c->cont.valid = false;
   memcpy(c->on_row_pin, row_host, (size_t)ld * sizeof(float));
   memcpy(c->on_idx_pin, idx_host, (size_t)n * sizeof(long long));
   const int total = n * (int)(ld / 4);
@@ -1029,6 +1058,7 @@ extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, con
   if (rc) return rc;
   DevGuard guard(c->device);
   hipStream_t st = (hipStream_t)stream;
+  c->cont.valid = false;                 // (the staging buffers / keep-bits a following train_steps call might continue from)
   const float* xb_cur = nullptr;
   rc = stage_batch(c, b, st, &xb_cur);
   if (rc) return rc;
@@ -1085,75 +1115,164 @@ extern "C" int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, ui
 }
 
 // ---------------------------------------------------------------------------
-// The multi-step driver.  A call of n steps = floor(n / GRAPH_STEPS) replays of ONE captured chunk graph +
-// n % GRAPH_STEPS steps launched directly; both run the same launch sequence (enqueue_chunk) and read their
-// per-launch values (buffer size, RNG position, scalar table slice, ring position, exchange step) from device words
-// that iql_chunk_setup_kernel rewrites in front of every chunk.
-static int enqueue_chunk(iqlhip_ctx* c, hipStream_t st, const float* rows_dev, int B, int K, float inv_batch, int mode,
-                         int parity, const ChunkHdr* h, const iqlhip_step_scalars* sched_src) {
-  // one launch: the chunk's K * B row indices + the rows of step 0 (step k+1's rows are staged by the idle blocks of
-  // forward k into the other of the two staging buffers; forward k and backward k read buffer k & 1).  A directly
-  // launched chunk (h != null) hands its per-launch values to that kernel as arguments; a captured one reads them
-  // from the device words iql_chunk_setup_kernel writes in front of every replay.
-  {
-    const long long n = (long long)K * B;
-    const int nb = (int)std::min<long long>((n / 2 + 255) / 256 + 1, 1024);
-    if (h)
-      hipLaunchKernelGGL(iql_chunk_prologue_kernel<true>, dim3(nb), dim3(256), 0, st, c->hdr, *h, c->sched_cur, sched_src,
-                         K, c->idx_chunk, n, rows_dev, (long long)c->row_ld, c->xb, B);
-    else {
-      ChunkHdr none;
-      memset(&none, 0, sizeof none);
-      hipLaunchKernelGGL(iql_chunk_prologue_kernel<false>, dim3(nb), dim3(256), 0, st, c->hdr, none, c->sched_cur,
-                         (const iqlhip_step_scalars*)nullptr, 0, c->idx_chunk, n, rows_dev, (long long)c->row_ld, c->xb, B);
-    }
+// The multi-step driver.  A call of n steps = ONE directly launched set-up kernel (header words, the call's scalar
+// table, step 0's rows unless the previous call left them staged) + replays of the fixed chunk graphs.  Everything a
+// replay needs to differ in lives in device words that the set-up kernel writes once and each chunk's last update
+// kernel advances, so the chunks of a call follow each other with no host-side launch in between; the rows, scalars and
+// keep-bits of step k + 1 are staged by the idle eighth of step k's forward grid (IdleWork).
+static void fill_idle_work(const iqlhip_ctx* c, IdleWork* w, const float* rows_dev, int B, int K) {
+  const int MB = c->dims.max_batch;
+  for (int k = 0; k < K; ++k) {
+    IdleWork& i = w[k];
+    memset(&i, 0, sizeof i);
+    i.rows = rows_dev;
+    i.ld = c->row_ld;
+    i.xb_dst = (k & 1) ? c->xb : c->xb2;              // step k reads buffer k & 1, step k + 1 the other one
+    i.hdr = c->hdr;
+    i.sched_call = c->sched_call;
+    i.sched_dst = c->sched_cur + k;
+    i.drop_dst = (c->drop_p > 0.f) ? c->drop_bits + (size_t)((k + 1) & 1) * 2 * MB * 8 : nullptr;
+    i.drop_words = 2 * MB * 8;
+    i.drop_thresh = drop_thresh(c->drop_p);
+    i.n = B;
+    i.k = k;
   }
-  if (c->drop_p > 0.f) launch_dropmask(c, 0, 0, c->hdr, 0, st);   // keep-bits of step 0 (seed / first step from hdr)
+}
+
+static int enqueue_chunk(iqlhip_ctx* c, hipStream_t st, int B, int K, float inv_batch, int mode, int parity,
+                         const IdleWork* work_dev) {
+  const int MB = c->dims.max_batch;
   iqlhip_step_scalars sc0;
   memset(&sc0, 0, sizeof sc0);
   sc0.inv_batch = inv_batch;
   for (int k = 0; k < K; ++k) {
     StepParams p = make_step(c, B, inv_batch);
     p.xb = (k & 1) ? c->xb2 : c->xb;
+    if (p.drop_bits) p.drop_bits = c->drop_bits + (size_t)(k & 1) * 2 * MB * 8;
+    p.g_work = work_dev + k;
     UpdParams u = make_upd(c, &sc0, B, nullptr);
     u.sched = c->sched_cur;
     u.sched_idx = k;
     u.loss_ring = c->loss_ring;
     u.ring_slot = k;
     u.ring_hdr = c->hdr;
-    if (k + 1 < K) {
-      p.g_rows = rows_dev; p.g_idx = c->idx_chunk + (long long)(k + 1) * B; p.g_n = B;
-      p.g_xb = (k & 1) ? c->xb : c->xb2;
-      if (c->drop_p > 0.f) { u.d_bits = c->drop_bits; u.d_thresh = drop_thresh(c->drop_p); u.d_k = k + 1; }
-    }
+    if (k + 1 == K) { u.adv_hdr = c->hdr; u.adv_k = K; u.adv_rows = B; }
     int rc = enqueue_step(c, p, u, mode, parity, k, /*from_hdr=*/true, st, nullptr);
     if (rc) return rc;
   }
   return IQLHIP_OK;
 }
 
+// A pinned table slot that no queued set-up kernel still has to read.
+static int acquire_sched_slot(iqlhip_ctx* c, int* slot_out) {
+  const int slot = c->sched_slot;
+  c->sched_slot = (c->sched_slot + 1) & 3;
+  const volatile unsigned long long* ack = c->sched_ack + slot;
+  if (*ack < c->sched_want[slot]) {
+    // (four calls deep in flight: wait for that set-up kernel — it runs at the head of its call — then re-check)
+    for (int spin = 0; spin < 20000 && *ack < c->sched_want[slot]; ++spin) { /* ~ a few tens of us */ }
+    if (*ack < c->sched_want[slot] && c->sched_stream[slot]) HIPCHK(hipStreamSynchronize(c->sched_stream[slot]));
+  }
+  *slot_out = slot;
+  return IQLHIP_OK;
+}
+
+// The set-up launch of a call (iql_call_setup_kernel): header, scalar table, and (gather) step 0's rows + keep-bits.
+// Its arguments as values + the pointer array both launch forms take: a direct launch, or — head chunk graphs, whose
+// first node is this kernel — hipGraphExecKernelNodeSetParams in front of the replay.
+struct SetupArgs {
+  unsigned long long* hdr; ChunkHdr h; iqlhip_step_scalars* sched_call; const iqlhip_step_scalars* sched_src; int n_steps;
+  const float* rows; long long ld; float* xb; int B; unsigned* drop_dst; int drop_words; unsigned drop_thresh;
+  unsigned* arrivals; unsigned long long* ack; unsigned long long ack_val;
+  void* ptrs[15];
+  int nb;
+};
+static void fill_setup_args(iqlhip_ctx* c, SetupArgs& a, const ChunkHdr& h, int slot, int n_steps, const float* rows_dev,
+                            int B, bool gather, hipStream_t st) {
+  const int MB = c->dims.max_batch;
+  const bool drop = gather && c->drop_p > 0.f;
+  if (slot >= 0) {
+    c->sched_want[slot] = ++c->call_seq;
+    c->sched_stream[slot] = st;
+  }
+  a.hdr = c->hdr; a.h = h; a.sched_call = c->sched_call; a.sched_src = slot >= 0 ? c->sched_pin[slot] : c->sched_pin[0];
+  a.n_steps = slot >= 0 ? n_steps : 0;
+  a.rows = rows_dev; a.ld = (long long)c->row_ld; a.xb = c->xb; a.B = gather ? B : 0;
+  a.drop_dst = drop ? c->drop_bits : nullptr; a.drop_words = 2 * MB * 8; a.drop_thresh = drop_thresh(c->drop_p);
+  a.arrivals = c->setup_arrivals;
+  a.ack = slot >= 0 ? c->sched_ack + slot : c->sched_ack + 4;        // (slot < 0: a capture-time placeholder, word 4 is a dummy)
+  a.ack_val = slot >= 0 ? c->sched_want[slot] : 0ull;
+  void* p[15] = {&a.hdr, &a.h, &a.sched_call, &a.sched_src, &a.n_steps, &a.rows, &a.ld, &a.xb, &a.B, &a.drop_dst,
+                 &a.drop_words, &a.drop_thresh, &a.arrivals, &a.ack, &a.ack_val};
+  memcpy(a.ptrs, p, sizeof p);
+  long long want = ((long long)n_steps * 3 + 255) / 256;
+  if (gather) want = std::max(want, ((long long)B * (c->row_ld / 4) + 255) / 256);
+  if (drop) want += (2 * MB * 8 + 255) / 256;
+  a.nb = (int)std::max<long long>(1, std::min<long long>(want, 256));
+}
+static int launch_call_setup(iqlhip_ctx* c, hipStream_t st, const ChunkHdr& h, int slot, int n_steps,
+                             const float* rows_dev, int B, bool gather) {
+  SetupArgs a;
+  fill_setup_args(c, a, h, slot, n_steps, rows_dev, B, gather, st);
+  HIPCHK(hipLaunchKernel((const void*)iql_call_setup_kernel, dim3(a.nb), dim3(256), a.ptrs, 0, st));
+  return IQLHIP_OK;
+}
+
 static int chunk_graph(iqlhip_ctx* c, const GraphKey& key, hipGraphExec_t* out, iqlhip_ctx::CachedGraph** slot) {
   for (auto& g : c->graphs)
     if (g.key == key) { g.stamp = ++c->graph_clock; *out = g.exec; if (slot) *slot = &g; return IQLHIP_OK; }
-  if (c->graphs.size() >= 8) {   // evict the least recently used — after its last replay has finished
+  if (c->graphs.size() >= 12) {   // evict the least recently used — after its last replay has finished
     size_t lru = 0;
     for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].stamp < c->graphs[lru].stamp) lru = i;
     if (c->graphs[lru].last) HIPCHK(hipStreamSynchronize(c->graphs[lru].last));
     (void)hipGraphExecDestroy(c->graphs[lru].exec);
     (void)hipGraphDestroy(c->graphs[lru].graph);
+    if (c->graphs[lru].work) (void)hipFree(c->graphs[lru].work);
     c->graphs.erase(c->graphs.begin() + lru);
+  }
+  // the chunk's idle-work records: device memory written once, here (their content is part of what the key freezes)
+  IdleWork* work = nullptr;
+  {
+    std::vector<IdleWork> hw((size_t)key.K);
+    fill_idle_work(c, hw.data(), key.rows, key.B, key.K);
+    HIPCHK(hipMalloc((void**)&work, hw.size() * sizeof(IdleWork)));
+    hipError_t e = hipMemcpy(work, hw.data(), hw.size() * sizeof(IdleWork), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(work); return fail(IQLHIP_EHIP, "chunk_graph: hipMemcpy: %s", hipGetErrorString(e)); }
   }
   hipStream_t cs = c->cap_stream;
   // (relaxed: a collective library may make calls during capture that the stricter modes forbid)
-  HIPCHK(hipStreamBeginCapture(cs, key.xch == IQLHIP_XCH_RCCL ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
-  int rc = enqueue_chunk(c, cs, key.rows, key.B, key.K, key.inv_batch, key.xch, key.parity, nullptr, nullptr);
+  hipError_t e = hipStreamBeginCapture(cs, key.xch == IQLHIP_XCH_RCCL ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { (void)hipFree(work); return fail(IQLHIP_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+  int rc = IQLHIP_OK;
+  if (key.head) {        // placeholder arguments: every replay sets the real ones (grid included)
+    ChunkHdr h0;
+    memset(&h0, 0, sizeof h0);
+    h0.w[HDR_SIZE] = 1ull;
+    SetupArgs a;
+    fill_setup_args(c, a, h0, -1, 0, key.rows, key.B, true, cs);
+    if (hipLaunchKernel((const void*)iql_call_setup_kernel, dim3(a.nb), dim3(256), a.ptrs, 0, cs) != hipSuccess)
+      rc = fail(IQLHIP_EHIP, "capture of the set-up kernel failed");
+  }
+  if (!rc) rc = enqueue_chunk(c, cs, key.B, key.K, key.inv_batch, key.xch, key.parity, work);
   hipGraph_t graph = nullptr;
-  hipError_t e = hipStreamEndCapture(cs, &graph);
-  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-  if (e != hipSuccess) return fail(IQLHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  e = hipStreamEndCapture(cs, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); (void)hipFree(work); return rc; }
+  if (e != hipSuccess) { (void)hipFree(work); return fail(IQLHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
   hipGraphExec_t gexec = nullptr;
-  HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
-  c->graphs.push_back({key, graph, gexec, ++c->graph_clock, nullptr});
+  e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(graph); (void)hipFree(work); return fail(IQLHIP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+  hipGraphNode_t setup_node = nullptr;
+  if (key.head) {
+    size_t n_root = 1;
+    e = hipGraphGetRootNodes(graph, &setup_node, &n_root);
+    hipGraphNodeType ty = hipGraphNodeTypeEmpty;
+    if (e == hipSuccess && n_root == 1) e = hipGraphNodeGetType(setup_node, &ty);
+    if (e != hipSuccess || n_root != 1 || ty != hipGraphNodeTypeKernel) {
+      (void)hipGraphExecDestroy(gexec); (void)hipGraphDestroy(graph); (void)hipFree(work);
+      return fail(IQLHIP_EHIP, "head chunk graph: no single kernel root node");
+    }
+  }
+  c->graphs.push_back({key, graph, gexec, ++c->graph_clock, nullptr, work, setup_node});
   *out = gexec;
   if (slot) *slot = &c->graphs.back();
   return IQLHIP_OK;
@@ -1169,12 +1288,38 @@ static int check_train_args(const iqlhip_ctx* c, const float* rows_dev, int64_t 
 }
 
 static GraphKey make_key(const iqlhip_ctx* c, const float* rows_dev, int64_t ld, int32_t B, int32_t K, float inv_batch,
-                         int parity) {
+                         int parity, int head = 0) {
   GraphKey key;
+  key.head = head;
   key.rows = rows_dev; key.ld = ld; key.B = B; key.K = K; key.params = c->params; key.drop_p = c->drop_p;
   key.inv_batch = inv_batch; key.xch = c->xch_mode;
   key.parity = (c->xch_mode == IQLHIP_XCH_P2P) ? parity : 0;
   return key;
+}
+
+// Replay one chunk graph on `st`.  head: the call's first chunk — its set-up node gets this call's arguments first.
+static const bool g_no_head_graph = getenv("IQLHIP_NO_HEAD_GRAPH") != nullptr;     // diagnostic: direct set-up launch + plain chunk
+static int replay_chunk(iqlhip_ctx* c, hipStream_t st, const float* rows_dev, int64_t ld, int B, int n, float inv_batch,
+                        const SetupArgs* head_args) {
+  const int parity = (int)(c->xstep & 1ull);
+  hipGraphExec_t gexec = nullptr;
+  iqlhip_ctx::CachedGraph* cg = nullptr;
+  int r = chunk_graph(c, make_key(c, rows_dev, ld, B, n, inv_batch, parity, head_args ? 1 : 0), &gexec, &cg);
+  if (r) return r;
+  if (head_args) {
+    hipKernelNodeParams np;
+    memset(&np, 0, sizeof np);
+    np.func = (void*)iql_call_setup_kernel;
+    np.gridDim = dim3(head_args->nb);
+    np.blockDim = dim3(256);
+    np.kernelParams = const_cast<void**>(head_args->ptrs);
+    HIPCHK(hipGraphExecKernelNodeSetParams(gexec, cg->setup_node, &np));
+  }
+  HIPCHK(hipGraphLaunch(gexec, st));
+  cg->last = st;
+  c->drop_step += (unsigned long long)n;
+  if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += (unsigned long long)n;
+  return IQLHIP_OK;
 }
 
 extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, int64_t ld, int32_t B, float inv_batch) {
@@ -1182,6 +1327,7 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
   if (rc) return rc;
   DevGuard guard(c->device);
   HIPCHK(hipDeviceSynchronize());       // a one-off set-up call: ordered after everything queued on any stream
+  c->cont.valid = false;
   hipStream_t cs = c->cap_stream;
   // Each chunk graph is captured, instantiated, uploaded AND replayed once, so that its first replay inside a caller's
   // timed region costs what every later one does (a first replay is ~50-100 us slower, and the first launch of a
@@ -1205,48 +1351,43 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
   };
   hipError_t e = copy_all(false);
   if (e != hipSuccess) { (void)hipFree(save); return fail(IQLHIP_EHIP, "prepare: save arenas: %s", hipGetErrorString(e)); }
-  const int slot = c->sched_slot;
-  c->sched_slot = (c->sched_slot + 1) & 3;
-  rc = IQLHIP_OK;
+  int slot = 0;
+  rc = acquire_sched_slot(c, &slot);
+  if (rc) { (void)hipFree(save); return rc; }
+  const unsigned long long drop_step0 = c->drop_step;
   do {
-    if (hipEventSynchronize(c->sched_done[slot]) != hipSuccess) { rc = fail(IQLHIP_EHIP, "prepare: event"); break; }
     iqlhip_step_scalars benign;
     memset(&benign, 0, sizeof benign);
     benign.bc2_sqrt[0] = benign.bc2_sqrt[1] = benign.bc2_sqrt[2] = 1.f;
     benign.beta2 = 1.f; benign.eps = 1e-8f; benign.grad_scale = 1.f; benign.inv_batch = inv_batch;
     for (int k = 0; k < GRAPH_STEPS; ++k) c->sched_pin[slot][k] = benign;
-    for (int K : {GRAPH_STEPS, GRAPH_STEPS_SMALL}) {
-      for (int rep = 0; rep < ((c->xch_mode == IQLHIP_XCH_P2P) ? 2 : 1) && !rc; ++rep) {
-        const int parity = (int)(c->xstep & 1ull);     // P2P: K is even, so the second graph is reached by one
-        hipGraphExec_t gexec = nullptr;               // extra directly launched step between the two rehearsals
-        iqlhip_ctx::CachedGraph* cg = nullptr;
-        rc = chunk_graph(c, make_key(c, rows_dev, ld, B, K, inv_batch, parity), &gexec, &cg);
-        if (rc) break;
-        if (hipGraphUpload(gexec, cs) != hipSuccess) { rc = fail(IQLHIP_EHIP, "hipGraphUpload failed"); break; }
-        ChunkHdr h;
-        memset(&h, 0, sizeof h);
-        h.w[HDR_SIZE] = 1ull;
-        h.w[HDR_DROP_STEP] = c->drop_step;
-        h.w[HDR_DROP_SEED] = c->drop_seed;
-        h.w[HDR_XSTEP] = c->xstep;
-        hipLaunchKernelGGL(iql_chunk_setup_kernel, dim3(1), dim3(256), 0, cs, c->hdr, h, c->sched_cur,
-                           (const iqlhip_step_scalars*)c->sched_pin[slot], K);
-        if (hipGraphLaunch(gexec, cs) != hipSuccess) { rc = fail(IQLHIP_EHIP, "prepare: hipGraphLaunch failed"); break; }
-        cg->last = cs;
-        if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += (unsigned long long)K;
-        if (c->xch_mode == IQLHIP_XCH_P2P && rep == 0) {
-          // one directly launched step flips the buffer parity for the other captured variant
-          ChunkHdr h1 = h;
-          h1.w[HDR_XSTEP] = c->xstep;
-          rc = enqueue_chunk(c, cs, rows_dev, B, 1, inv_batch, c->xch_mode, (int)(c->xstep & 1ull), &h1, c->sched_pin[slot]);
-          if (rc) break;
-          c->xstep += 1ull;
-        }
+    // every chunk graph once: the head chunks (2 steps, and the one-step call's) with their set-up node, the plain ones
+    // behind a directly launched set-up kernel.  P2P: a one-step chunk flips the buffer parity, so a second pass over
+    // the same list reaches the other captured variant of each.
+    const int passes = (c->xch_mode == IQLHIP_XCH_P2P) ? 2 : 1;
+    struct Item { int K; int head; };
+    const Item items[] = {{2, 1}, {GRAPH_STEPS, 0}, {16, 0}, {4, 0}, {2, 0}, {1, 0}};
+    auto rehearse = [&](const Item& it) -> int {
+      ChunkHdr h;
+      memset(&h, 0, sizeof h);
+      h.w[HDR_SIZE] = 1ull;
+      h.w[HDR_DROP_STEP] = c->drop_step;
+      h.w[HDR_DROP_SEED] = c->drop_seed;
+      h.w[HDR_XSTEP] = c->xstep;
+      if (it.head && !g_no_head_graph) {
+        SetupArgs a;
+        fill_setup_args(c, a, h, slot, it.K, rows_dev, B, /*gather=*/true, cs);
+        return replay_chunk(c, cs, rows_dev, ld, B, it.K, inv_batch, &a);
       }
-      if (rc) break;
-    }
+      int r = launch_call_setup(c, cs, h, slot, it.K, rows_dev, B, /*gather=*/true);
+      if (r) return r;
+      return replay_chunk(c, cs, rows_dev, ld, B, it.K, inv_batch, nullptr);
+    };
+    for (int pass = 0; pass < passes && !rc; ++pass)
+      for (const Item& it : items) { rc = rehearse(it); if (rc) break; }
+    for (int pass = 0; pass < passes && !rc; ++pass) rc = rehearse(Item{1, 1});
   } while (0);
-  (void)hipEventRecord(c->sched_done[slot], cs);
+  c->drop_step = drop_step0;            // (the rehearsal drew keep-bits from the stream's current position; it is not advanced)
   e = copy_all(true);
   hipError_t e2 = hipStreamSynchronize(cs);
   (void)hipFree(save);
@@ -1257,19 +1398,21 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
 
 extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t ld, int64_t size, int32_t B,
                                   const iqlhip_step_scalars* sc, int32_t K, uint64_t seed, uint64_t stream_offset,
-                                  void* stream) {
+                                  int32_t flags, void* stream) {
   if (!sc) return fail(IQLHIP_EINVAL, "NULL argument");
   int rc = check_train_args(c, rows_dev, ld, B);
   if (rc) return rc;
   if (K < 1 || K > c->k_max) return fail(IQLHIP_EINVAL, "n_steps outside [1,%d]", c->k_max);
   if (size < 1) return fail(IQLHIP_EINVAL, "empty buffer");
+  double tr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (g_trace) tr_t[0] = now_us();
   DevGuard guard(c->device);
   hipStream_t st = (hipStream_t)stream;
-  // the call's scalar table goes into a pinned, host-mapped slot that the chunk setup kernels read in place; a slot is
-  // reused only after the call that used it has drained (event), so the caller's array is free on return
-  const int slot = c->sched_slot;
-  c->sched_slot = (c->sched_slot + 1) & 3;
-  HIPCHK(hipEventSynchronize(c->sched_done[slot]));
+  // the call's scalar table goes into a pinned, host-mapped slot that the set-up kernel reads in place; a slot is
+  // reused only after the set-up kernel that read it has run (event), so the caller's array is free on return
+  int slot = 0;
+  rc = acquire_sched_slot(c, &slot);
+  if (rc) return rc;
   memcpy(c->sched_pin[slot], sc, (size_t)K * sizeof(iqlhip_step_scalars));
   const float inv_batch = sc[0].inv_batch;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1279,40 +1422,54 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
     ev0 = c->ev[c->ev_used]; ev1 = c->ev[c->ev_used + 1];
     HIPCHK(hipEventRecord(ev0, st));
   }
-  int done = 0;
-  while (done < K) {
-    const int left = K - done;
-    const int n = left >= GRAPH_STEPS ? GRAPH_STEPS : (left >= GRAPH_STEPS_SMALL ? GRAPH_STEPS_SMALL : left);
-    ChunkHdr h;
-    memset(&h, 0, sizeof h);
-    h.w[HDR_SIZE] = (unsigned long long)size;
-    h.w[HDR_SEED] = (unsigned long long)seed;
-    // one Philox counter yields two indices; `done` is a multiple of GRAPH_STEPS_SMALL (even), so a chunk starts on a
-    // counter boundary and the call's index stream is the one a single draw of K * B indices would give
-    h.w[HDR_OFFSET] = (unsigned long long)stream_offset + ((unsigned long long)done * (unsigned long long)B) / 2ull;
-    h.w[HDR_DROP_STEP] = c->drop_step;
-    h.w[HDR_DROP_SEED] = c->drop_seed;
-    h.w[HDR_BASE] = (unsigned long long)done;
-    h.w[HDR_XSTEP] = c->xstep;
-    const iqlhip_step_scalars* src = c->sched_pin[slot] + done;
-    const int parity = (int)(c->xstep & 1ull);
-    if (n == GRAPH_STEPS || n == GRAPH_STEPS_SMALL) {
-      hipGraphExec_t gexec = nullptr;
-      iqlhip_ctx::CachedGraph* cg = nullptr;
-      rc = chunk_graph(c, make_key(c, rows_dev, ld, B, n, inv_batch, parity), &gexec, &cg);
-      if (rc) return rc;
-      hipLaunchKernelGGL(iql_chunk_setup_kernel, dim3(1), dim3(256), 0, st, c->hdr, h, c->sched_cur, src, n);
-      HIPCHK(hipGraphLaunch(gexec, st));
-      cg->last = st;
-    } else {
-      rc = enqueue_chunk(c, st, rows_dev, B, n, inv_batch, c->xch_mode, parity, &h, src);
-      if (rc) return rc;
-    }
-    c->drop_step += (unsigned long long)n;
-    if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += (unsigned long long)n;
-    done += n;
+  // does this call continue the previous one's index stream with its step 0 already staged?
+  const bool cont = (flags & IQLHIP_TS_CONTINUE) && c->cont.valid && c->cont.rows == rows_dev && c->cont.ld == ld &&
+                    c->cont.size == size && c->cont.B == B && c->cont.seed == seed && c->cont.next_offset == stream_offset &&
+                    c->cont.drop_p == c->drop_p && c->cont.drop_seed == c->drop_seed && c->cont.drop_step == c->drop_step;
+  c->cont.valid = false;
+  ChunkHdr h;
+  memset(&h, 0, sizeof h);
+  h.w[HDR_SIZE] = (unsigned long long)size;
+  h.w[HDR_SEED] = (unsigned long long)seed;
+  h.w[HDR_OFFSET] = (unsigned long long)stream_offset;     // index j of the call = counter offset + j / 2, pair word j & 1
+  h.w[HDR_DROP_STEP] = c->drop_step;
+  h.w[HDR_DROP_SEED] = c->drop_seed;
+  h.w[HDR_XSTEP] = c->xstep;
+  if (g_trace) tr_t[1] = now_us();
+  // The call's first chunk is a HEAD chunk — 2 steps (1 for a one-step call) behind the set-up kernel, in one graph whose
+  // set-up node gets this call's arguments: one host-side launch until the GPU has work, and a short one (a graph
+  // launch costs ~10 us + 0.4 us per node on the host; the GPU starts when it returns).  The rest follows as plain
+  // chunks, the even sizes ascending (each launch is hidden behind the execution of what was launched before), the
+  // 64-step chunk as often as it fits, a one-step chunk — odd calls only — last.
+  int rem;
+  if (g_no_head_graph) {
+    rc = launch_call_setup(c, st, h, slot, K, rows_dev, B, /*gather=*/!cont);
+    if (rc) return rc;
+    rem = K;
+  } else {
+    const int head_k = (K >= 2) ? 2 : 1;
+    SetupArgs a;
+    fill_setup_args(c, a, h, slot, K, rows_dev, B, /*gather=*/!cont, st);
+    rc = replay_chunk(c, st, rows_dev, ld, B, head_k, inv_batch, &a);
+    if (rc) return rc;
+    rem = K - head_k;
   }
-  HIPCHK(hipEventRecord(c->sched_done[slot], st));
+  if (g_trace) tr_t[2] = tr_t[3] = now_us();
+  const int n64 = rem / GRAPH_STEPS;
+  rem %= GRAPH_STEPS;
+  int small[8], ns = 0;
+  for (int cs_ : {16, 4, 2, 1}) while (rem >= cs_) { small[ns++] = cs_; rem -= cs_; }     // (<= 3 + 3 + 1 + 1 entries)
+  for (int i = ns - 1; i >= 0; --i) if (small[i] != 1) { rc = replay_chunk(c, st, rows_dev, ld, B, small[i], inv_batch, nullptr); if (rc) return rc; }
+  for (int i = 0; i < n64; ++i) { rc = replay_chunk(c, st, rows_dev, ld, B, GRAPH_STEPS, inv_batch, nullptr); if (rc) return rc; }
+  if (ns > 0 && small[ns - 1] == 1) { rc = replay_chunk(c, st, rows_dev, ld, B, 1, inv_batch, nullptr); if (rc) return rc; }
+  // what a following call must look like to start on the rows this call's last forward has staged: an even number of
+  // steps ends on staging buffer 0, where a chunk's step 0 reads; the next counter follows from the rows drawn
+  if ((K & 1) == 0 && (((unsigned long long)K * (unsigned long long)B) & 1ull) == 0) {
+    c->cont.valid = true;
+    c->cont.rows = rows_dev; c->cont.ld = ld; c->cont.size = size; c->cont.B = B; c->cont.seed = seed;
+    c->cont.next_offset = stream_offset + ((unsigned long long)K * (unsigned long long)B) / 2ull;
+    c->cont.drop_p = c->drop_p; c->cont.drop_seed = c->drop_seed; c->cont.drop_step = c->drop_step;
+  }
   if (ev0) {
     HIPCHK(hipEventRecord(ev1, st));
     HIPCHK(hipEventSynchronize(ev1));
@@ -1322,6 +1479,9 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
     c->t_n += 1;
   }
   HIPCHK(hipGetLastError());
+  if (g_trace)
+    fprintf(stderr, "[iqlhip trace] train_steps K=%d cont=%d: entry->launch %.1f us, head chunk (set-up + launch) %.1f, rest %.1f\n",
+            K, (int)cont, tr_t[1] - tr_t[0], tr_t[2] - tr_t[1], now_us() - tr_t[3]);
   return IQLHIP_OK;
 }
 
@@ -1514,6 +1674,19 @@ static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld
   return IQLHIP_OK;
 }
 
+// Diagnostic: queue a kernel that writes a fresh number into a host-mapped word, then spin on that word from the host
+// (no HIP call): *spin_us = time until the GPU has drained `stream`, as the host sees it without any synchronise call.
+extern "C" int iqlhip_debug_drain_spin(iqlhip_ctx* c, void* stream, double* spin_us) {
+  if (!c || !spin_us) return fail(IQLHIP_EINVAL, "NULL argument");
+  const double t0 = now_us();
+  const unsigned long long v = ++c->call_seq;
+  hipLaunchKernelGGL(iql_debug_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->sched_ack + 5, v);
+  const volatile unsigned long long* f = c->sched_ack + 5;
+  while (*f != v) { if (now_us() - t0 > 5e6) return fail(IQLHIP_EHIP, "drain_spin: timeout"); }
+  *spin_us = now_us() - t0;
+  return IQLHIP_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Micro-benchmark hook: launch ONE kernel of the step `repeat` times back to back and return the
 // average time per launch (hipEvents on `stream`).  which: 0 fwd, 1 bwd, 2 update (no-op scalars:
@@ -1524,6 +1697,7 @@ extern "C" int iqlhip_debug_time_kernel(iqlhip_ctx* c, const iqlhip_batch* b, in
   int rc = check_batch(c, b);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  c->cont.valid = false;
   const float* xb_cur = nullptr;
   rc = stage_batch(c, b, st, &xb_cur);
   if (rc) return rc;

@@ -152,14 +152,12 @@ struct StepParams {
   // built once and 2 or 4 of the 64-column slices are walked with it (host: launch_bwd).  (One word for both: a
   // second one grew the kernel-argument block past 0x478 bytes and every backward launch took 0.17 us longer.)
   int spb_l2;
-  // next step's batch (hipGraph chunks): the forward's idle blocks (blockIdx & 7 == 7, one per row tile and column
-  // slice) copy rows[idx[r]] -> g_xb[r] (whole padded rows) into the OTHER staging buffer while the 7 instances run.
-  // In the update kernel the two dependent HBM round trips (index, then row) stretched that kernel by ~0.8 us.
-  const float* g_rows;
-  long long g_ld;
-  const long long* g_idx;   // nullable: nothing to gather
-  float* g_xb;
-  int g_n;
+  // hipGraph chunks: what the forward's idle blocks (blockIdx & 7 == 7, one per row tile and column slice) do while the 7
+  // instances run — stage the NEXT step's rows (indices drawn on the spot) into the other staging buffer, copy this
+  // step's optimiser scalars into place, draw the next step's dropout keep-bits.  One pointer to a device-resident
+  // record (frozen per captured step) instead of the fields themselves: the kernel-argument block stays below the
+  // size at which every backward launch was measured 0.17 us slower (0x480 bytes).  Null: nothing to do.
+  const struct IdleWork* g_work;
 };
 
 // Force kernel-argument fields into SGPRs NOW.  hipcc sinks each s_load next to its first use, which
@@ -218,6 +216,109 @@ __device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld
   }
 }
 
+// ---------------------------------------------------------------------------
+// Device words a run of steps (hipGraph chunks) reads its per-launch values from: kernel arguments of a captured graph
+// are frozen, these words are not.  iql_call_setup_kernel writes them ONCE per iqlhip_train_steps call; every chunk
+// then advances them itself (thread 0 of its last update kernel: POS, DROP_STEP, BASE, XSTEP), so the chunks of a
+// call chain on the device with no host-side launch between them.
+//   SIZE      rows the index draw covers           SEED / OFFSET  Philox key / the call's first counter
+//   POS       indices drawn before this chunk (index j of the call = counter OFFSET + j / 2, word pair j & 1)
+//   BASE      steps of the call before this chunk (row of the call's scalar table, slot of the loss ring)
+//   DROP_*    dropout stream                        XSTEP          steps exchanged before this chunk (P2P flags)
+enum { HDR_SIZE = 0, HDR_SEED = 1, HDR_OFFSET = 2, HDR_DROP_STEP = 3, HDR_DROP_SEED = 4, HDR_BASE = 5, HDR_XSTEP = 6,
+       HDR_POS = 7, HDR_WORDS = 8 };
+struct ChunkHdr { unsigned long long w[HDR_WORDS]; };
+
+// Philox4x32-10 (Salmon et al. 2011).
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// Dropout keep-bits for one step: word w (of n_words = 2 * max_batch * 8) gets 32 independent Bernoulli(1-p)
+// bits: keep iff u32 >= thresh (thresh = p * 2^32).  Stream: key = seed, counter = (word, call, step).
+__device__ __forceinline__ void dropmask_words(unsigned* bits, int n_words, unsigned thresh, unsigned long long seed,
+                                               unsigned long long step, int first, int stride) {
+  for (int w = first; w < n_words; w += stride) {
+    unsigned word = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t c[4] = {(uint32_t)w, (uint32_t)j | 0x44524F50u /* "DROP" */, (uint32_t)step, (uint32_t)(step >> 32)};
+      philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) word |= (c[q] >= thresh ? 1u : 0u) << (4 * j + q);
+    }
+    bits[w] = word;
+  }
+}
+
+// Index j of a call's draw: Philox4x32-10, counter = ctr0 + j / 2, key = seed; the counter's four words give two
+// indices, uniform over [0, size) by multiply-high of 64 random bits (bias <= size / 2^64) — the stream
+// iql_draw_indices_kernel writes out (np.random.randint's distribution, iql.py:172).
+__device__ __forceinline__ long long draw_index(unsigned long long seed, unsigned long long ctr0, unsigned long long j,
+                                                unsigned long long size) {
+  const unsigned long long ctr = ctr0 + (j >> 1);
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x49514C48u /* "IQLH" */, 0u};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const unsigned long long r = (j & 1ull) ? (((unsigned long long)c[3] << 32) | c[2]) : (((unsigned long long)c[1] << 32) | c[0]);
+  return (long long)__umul64hi(r, size);
+}
+
+// rows[draw(j0 + r)] -> xb[r], r < n: the gather of a step whose indices nobody stores — every thread of a row's
+// float4s draws that row's index itself (~150 ALU instructions instead of a dependent idx -> row round trip to HBM).
+__device__ __forceinline__ void gather_rows_drawn(const float* rows, long long ld, float* xb, int n, unsigned long long seed,
+                                                  unsigned long long ctr0, unsigned long long j0, unsigned long long size,
+                                                  int first, int stride) {
+  const int q = (int)(ld >> 2);
+  const int total = n * q;
+  for (int e = first; e < total; e += stride) {
+    const int r = e / q, c4 = e - r * q;
+    const long long i = draw_index(seed, ctr0, j0 + (unsigned long long)r, size);
+    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = *(const f32x4*)(rows + i * ld + 4 * c4);
+  }
+}
+
+// What the idle eighth of a captured step's forward grid does (StepParams::g_work; one record per step of a chunk,
+// written once when the chunk is captured):
+struct IdleWork {
+  const float* rows;                      // replay rows the NEXT step's batch is drawn from
+  long long ld;
+  float* xb_dst;                          // the staging buffer the next step reads (the other one of the two)
+  const unsigned long long* hdr;
+  const iqlhip_step_scalars* sched_call;  // the call's scalar table (device copy)
+  iqlhip_step_scalars* sched_dst;         // where THIS step's update kernel reads its scalars (frozen address)
+  unsigned* drop_dst;                     // keep-bits of the next step (the other parity's buffer); null: no dropout
+  int drop_words;
+  unsigned drop_thresh;
+  int n;                                  // rows per step
+  int k;                                  // this step's number inside the chunk
+};
+__device__ __forceinline__ void idle_block_work(const IdleWork* wk, int blk, int nblk) {
+  const IdleWork w = *wk;
+  const unsigned long long size = w.hdr[HDR_SIZE], seed = w.hdr[HDR_SEED], ctr0 = w.hdr[HDR_OFFSET], pos = w.hdr[HDR_POS];
+  const unsigned long long base = w.hdr[HDR_BASE], dseed = w.hdr[HDR_DROP_SEED], dstep = w.hdr[HDR_DROP_STEP];
+  // the next step's rows: index j = POS + (k + 1) n + r of the call (for the chunk's last step that is step 0 of
+  // whatever runs next: the following chunk, or the next call when it continues this one's stream)
+  gather_rows_drawn(w.rows, w.ld, w.xb_dst, w.n, seed, ctr0, pos + (unsigned long long)(w.k + 1) * (unsigned long long)w.n,
+                    size, blk * 256 + (int)threadIdx.x, nblk * 256);
+  // this step's optimiser scalars: row BASE + k of the call's table -> the slot this step's update kernel reads
+  if (blk == nblk - 1 && threadIdx.x < sizeof(iqlhip_step_scalars) / sizeof(float))
+    ((float*)w.sched_dst)[threadIdx.x] = ((const float*)(w.sched_call + base + (unsigned long long)w.k))[threadIdx.x];
+  // the next step's dropout keep-bits (the last blocks first: the gather occupies the first ones)
+  if (w.drop_dst)
+    dropmask_words(w.drop_dst, w.drop_words, w.drop_thresh, dseed, dstep + (unsigned long long)(w.k + 1),
+                   (nblk - 1 - blk) * 256 + (int)threadIdx.x, nblk * 256);
+}
+
 // Forward: block = (instance, row tile of 32 rows, column slice ns of 64 hidden-1 units).
 // grid = 8 * n_rt * NSPLIT; blockIdx & 7 = instance (7 = idle) so that the
 // blocks of one instance share an XCD and hence one L2 copy of its weights.
@@ -256,8 +357,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   const int bid = blockIdx.x;
   const int inst = ONE ? p.only_inst : (bid & 7);
   const int rest = ONE ? bid : (bid >> 3);
-  if (inst >= 7) {     // the idle eighth of the grid stages the NEXT step's rows (graph chunks), else exits
-    if (p.g_idx) gather_rows_flat(p.g_rows, p.g_ld, p.g_idx, p.g_xb, p.g_n, rest * 256 + (int)threadIdx.x, (int)(gridDim.x >> 3) * 256);
+  if (inst >= 7) {     // the idle eighth of the grid: the chunk's bookkeeping for the NEXT step (graph chunks), else exits
+    if (p.g_work) idle_block_work(p.g_work, rest, (int)(gridDim.x >> 3));
     return;
   }
   const int spb_l2 = MULTI ? (p.spb_l2 & 3) : 0;      // (MULTI = false: exactly the one-slice code, no loop)
@@ -1759,22 +1860,15 @@ struct UpdParams {
   int batch_rows;
   const iqlhip_step_scalars* sched;  // when non-null the scalars of this launch are sched[sched_idx]
   int sched_idx;                     // (hipGraph replay: kernel arguments are frozen, the table is not)
-  int n_upd_blocks;
-  // next step's dropout keep-bits: extra blocks after the optimizer blocks
-  unsigned* d_bits;         // nullable: no mask blocks
-  int d_n_words;
-  unsigned d_thresh;
-  const unsigned long long* d_hdr;
-  int d_k;
   // chunk replay: the loss-ring slot of this launch is ring_slot + ring_hdr[HDR_BASE] (the chunk's first step inside
   // the call; a captured chunk is replayed at different positions of the ring); null = ring_slot as given
   const unsigned long long* ring_hdr;
+  // the LAST update of a chunk moves the chunk header on by the chunk's adv_k steps of adv_rows rows (thread 0 of
+  // block 0, the only reader of the header in this kernel — every other reader belongs to an earlier or later
+  // kernel), so the next chunk of the call starts without a host-side launch in between; null elsewhere
+  unsigned long long* adv_hdr;
+  int adv_k, adv_rows;
 };
-
-// Device words a chunk of steps (captured in a hipGraph or launched eagerly) reads its per-launch values from: kernel
-// arguments of a captured graph are frozen, these words are rewritten by iql_chunk_setup_kernel before every replay.
-enum { HDR_SIZE = 0, HDR_SEED = 1, HDR_OFFSET = 2, HDR_DROP_STEP = 3, HDR_DROP_SEED = 4, HDR_BASE = 5, HDR_XSTEP = 6, HDR_WORDS = 8 };
-struct ChunkHdr { unsigned long long w[HDR_WORDS]; };
 
 __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
   int n = 0;
@@ -1841,38 +1935,6 @@ __device__ __forceinline__ void loss_words(const UpdParams& u, float out[4]) {
   out[3] = s[3];   // sum_r w bc
 }
 
-// Philox4x32-10 (Salmon et al. 2011).
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-
-// Dropout keep-bits for one step: word w (of n_words = 2 * max_batch * 8) gets 32 independent Bernoulli(1-p)
-// bits: keep iff u32 >= thresh (thresh = p * 2^32).  Stream: key = seed, counter = (word, call, step).
-__device__ __forceinline__ void dropmask_words(unsigned* bits, int n_words, unsigned thresh, unsigned long long seed,
-                                               unsigned long long step, int first, int stride) {
-  for (int w = first; w < n_words; w += stride) {
-    unsigned word = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      uint32_t c[4] = {(uint32_t)w, (uint32_t)j | 0x44524F50u /* "DROP" */, (uint32_t)step, (uint32_t)(step >> 32)};
-      philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) word |= (c[q] >= thresh ? 1u : 0u) << (4 * j + q);
-    }
-    bits[w] = word;
-  }
-}
-
 // `hdr` (nullable): device words {size, seed, offset, step0}: a captured graph is replayed with new values.
 __global__ __launch_bounds__(256) void iql_dropmask_kernel(unsigned* bits, int n_words, unsigned thresh,
                                                            unsigned long long seed, unsigned long long step,
@@ -1881,17 +1943,45 @@ __global__ __launch_bounds__(256) void iql_dropmask_kernel(unsigned* bits, int n
   dropmask_words(bits, n_words, thresh, seed, step, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-// Per-launch values of a chunk (see ChunkHdr) + the chunk's slice of the per-step scalar table: sched_src is the
-// library's pinned, host-mapped copy of the caller's table (read over PCIe: <= 64 x 48 B), sched_cur the fixed device
-// array the chunk's update kernels index with their frozen step number.
-__global__ __launch_bounds__(256) void iql_chunk_setup_kernel(unsigned long long* hdr, ChunkHdr h,
-                                                              iqlhip_step_scalars* sched_cur,
-                                                              const iqlhip_step_scalars* sched_src, int n) {
-  if (threadIdx.x < HDR_WORDS) hdr[threadIdx.x] = h.w[threadIdx.x];
-  const float* s = (const float*)sched_src;
-  float* d = (float*)sched_cur;
-  const int words = n * (int)(sizeof(iqlhip_step_scalars) / sizeof(float));
-  for (int i = threadIdx.x; i < words; i += 256) d[i] = s[i];
+// First launch of an iqlhip_train_steps call (the only one that is not part of a chunk): block 0 publishes the call's
+// header words; all blocks copy the call's scalar table from the library's pinned, host-mapped slot (read over PCIe,
+// n_steps x 48 B) into its device copy, and — unless the previous call left them staged (B == 0) — gather the rows
+// of the call's step 0 (indices drawn on the spot from the by-value header) and draw its dropout keep-bits.
+// The block that finishes last acknowledges the table read in a host-mapped word (`ack`): the host reuses the pinned
+// slot once it sees the call's number there — no event record in the stream, no HIP call on the host to test it.
+__global__ __launch_bounds__(256) void iql_call_setup_kernel(unsigned long long* hdr, ChunkHdr h,
+                                                             iqlhip_step_scalars* sched_call,
+                                                             const iqlhip_step_scalars* sched_src, int n_steps,
+                                                             const float* rows, long long ld, float* xb, int B,
+                                                             unsigned* drop_dst, int drop_words, unsigned drop_thresh,
+                                                             unsigned* arrivals, unsigned long long* ack,
+                                                             unsigned long long ack_val) {
+  if (blockIdx.x == 0 && threadIdx.x < HDR_WORDS) hdr[threadIdx.x] = h.w[threadIdx.x];
+  const f32x4* s = (const f32x4*)sched_src;
+  f32x4* d = (f32x4*)sched_call;
+  const int n4 = n_steps * (int)(sizeof(iqlhip_step_scalars) / sizeof(f32x4));
+  for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < n4; i += (int)gridDim.x * 256) d[i] = s[i];
+  // (a thread's stores carry the data its loads returned: once every thread of every block is past this point the
+  //  pinned slot has been read completely)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == gridDim.x) {
+      __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ack, ack_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (B > 0)
+    gather_rows_drawn(rows, ld, xb, B, h.w[HDR_SEED], h.w[HDR_OFFSET], h.w[HDR_POS], h.w[HDR_SIZE],
+                      (int)blockIdx.x * 256 + (int)threadIdx.x, (int)gridDim.x * 256);
+  if (drop_dst)
+    dropmask_words(drop_dst, drop_words, drop_thresh, h.w[HDR_DROP_SEED], h.w[HDR_DROP_STEP],
+                   ((int)gridDim.x - 1 - (int)blockIdx.x) * 256 + (int)threadIdx.x, (int)gridDim.x * 256);
+}
+
+// Diagnostic (tools/gpu_call_overhead.py): a host-mapped word that says "everything queued before me has run".
+__global__ void iql_debug_flag_kernel(unsigned long long* flag, unsigned long long v) {
+  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long long ld, const long long* idx,
@@ -1996,19 +2086,8 @@ __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, floa
 // arguments are frozen, the table is not); otherwise from the kernel argument u.sc.  Two instantiations
 // rather than a run-time pointer select, which would turn every access into a flat load.
 // PEER: the direct-read exchange variant (gradient = rank-ordered sum over UpdParams::peer_flat).
-// MASKS: the grid carries extra blocks for the next step's dropout keep-bits.  A template flag: as a run-time test it
-// was a scalar load + wait + branch in front of the argument batch in EVERY launch (cf. the forward's ONE flag).
-template <bool FROM_TABLE, bool PEER, bool MASKS = false>
+template <bool FROM_TABLE, bool PEER>
 __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
-  if (MASKS && (int)blockIdx.x >= u.n_upd_blocks) {
-    // extra blocks: the next step's dropout keep-bits while the optimizer blocks run (the next step's ROWS are
-    // staged by the forward kernel's idle blocks, see StepParams::g_idx)
-    const int mb = (int)blockIdx.x - u.n_upd_blocks;
-    const int nmb = (int)gridDim.x - u.n_upd_blocks;
-    dropmask_words(u.d_bits, u.d_n_words, u.d_thresh, u.d_hdr[HDR_DROP_SEED],
-                   u.d_hdr[HDR_DROP_STEP] + (unsigned long long)u.d_k, mb * 256 + threadIdx.x, nmb * 256);
-    return;
-  }
   // every kernel-argument word the optimizer path uses, fetched in ONE batch of scalar loads (hipcc otherwise sinks
   // each load next to its first use: five dependent scalar-cache misses in front of the gradient loads).  ONE asm
   // statement for all of them: a volatile asm per word is ordered against the others and gets its own wait.
@@ -2135,6 +2214,12 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
       float* rr = u.loss_ring + 4 * slot;
       rr[0] = l[0]; rr[1] = l[1]; rr[2] = l[2]; rr[3] = 0.f;
     }
+    if (u.adv_hdr) {      // the chunk is done: its successor finds its own per-launch values
+      u.adv_hdr[HDR_POS] += (unsigned long long)u.adv_k * (unsigned long long)u.adv_rows;
+      u.adv_hdr[HDR_DROP_STEP] += (unsigned long long)u.adv_k;
+      u.adv_hdr[HDR_BASE] += (unsigned long long)u.adv_k;
+      u.adv_hdr[HDR_XSTEP] += (unsigned long long)u.adv_k;
+    }
   }
 }
 
@@ -2233,57 +2318,6 @@ __global__ void iql_rows_gather_kernel(const float* rows, long long ld, int S, i
     else if (c < 2 * S + A) ns[i * S + (c - S - A)] = v;
     else if (c == 2 * S + A) r[i] = v;
     else d[i] = v;
-  }
-}
-
-// First launch of a chunk of steps: draws the chunk's n_idx row indices (same stream as iql_draw_indices_kernel) AND
-// gathers the rows of the chunk's step 0 into xb (the indices a block has just drawn travel through LDS), so that a
-// chunk starts with one launch instead of three.  SETUP (directly launched chunks): the per-launch values arrive as the
-// kernel argument `h`, and block 0 also publishes them (hdr words + the chunk's slice of the scalar table) for the
-// kernels that follow; !SETUP (captured chunks, frozen arguments): they are read from hdr, which
-// iql_chunk_setup_kernel has written in front of the replay.
-template <bool SETUP>
-__global__ __launch_bounds__(256) void iql_chunk_prologue_kernel(unsigned long long* hdr, ChunkHdr h,
-                                                                 iqlhip_step_scalars* sched_cur,
-                                                                 const iqlhip_step_scalars* sched_src, int n_sched,
-                                                                 long long* idx, long long n_idx, const float* rows,
-                                                                 long long ld, float* xb, int B) {
-  __shared__ long long s_idx[512];
-  unsigned long long size, seed, offset;
-  if (SETUP) {
-    size = h.w[HDR_SIZE]; seed = h.w[HDR_SEED]; offset = h.w[HDR_OFFSET];
-    if (blockIdx.x == 0) {
-      if (threadIdx.x < HDR_WORDS) hdr[threadIdx.x] = h.w[threadIdx.x];
-      const float* s = (const float*)sched_src;
-      float* d = (float*)sched_cur;
-      const int words = n_sched * (int)(sizeof(iqlhip_step_scalars) / sizeof(float));
-      for (int i = threadIdx.x; i < words; i += 256) d[i] = s[i];
-    }
-  } else {
-    size = hdr[HDR_SIZE]; seed = hdr[HDR_SEED]; offset = hdr[HDR_OFFSET];
-  }
-  const long long n_pairs = (n_idx + 1) / 2;
-  bool first = true;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_pairs; i += (long long)gridDim.x * 256) {
-    const unsigned long long ctr = offset + (unsigned long long)i;
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x49514C48u /* "IQLH" */, 0u};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const unsigned long long r0 = ((unsigned long long)c[1] << 32) | c[0];
-    const unsigned long long r1 = ((unsigned long long)c[3] << 32) | c[2];
-    const long long i0 = (long long)__umul64hi(r0, size), i1 = (long long)__umul64hi(r1, size);
-    idx[2 * i] = i0;
-    if (2 * i + 1 < n_idx) idx[2 * i + 1] = i1;
-    if (first) { s_idx[2 * threadIdx.x] = i0; s_idx[2 * threadIdx.x + 1] = i1; first = false; }
-  }
-  // rows [512 b, 512 b + 512) of step 0 belong to the pairs this block drew in its first pass
-  const int r_lo = (int)blockIdx.x * 512;
-  if (r_lo >= B) return;                 // (block-uniform)
-  __syncthreads();
-  const int q = (int)(ld >> 2);
-  const int n_r = min(512, B - r_lo);
-  for (int e = threadIdx.x; e < n_r * q; e += 256) {
-    const int r = e / q, c4 = e - r * q;
-    *(f32x4*)(xb + (long long)(r_lo + r) * ld + 4 * c4) = *(const f32x4*)(rows + s_idx[r] * ld + 4 * c4);
   }
 }
 

@@ -20,6 +20,7 @@ IQLHIP_GRAPH_STEPS = 64
 IQLHIP_UNIQUE_ID_BYTES = 128
 IQLHIP_IPC_HANDLE_BYTES = 64
 XCH_NONE, XCH_RCCL, XCH_P2P = 0, 1, 2
+TS_CONTINUE = 1
 NET_V, NET_Q1, NET_Q2, NET_PI = 0, 1, 2, 3
 POLICY_GAUSSIAN, POLICY_DETERMINISTIC = 0, 1
 
@@ -85,7 +86,7 @@ SYMBOLS = [
     ("iqlhip_apply_update", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StepScalars), C.c_void_p]),
     ("iqlhip_grad_words", C.c_int64, [C.c_void_p]),
     ("iqlhip_train_steps", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
-                                     C.POINTER(StepScalars), C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p]),
+                                     C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p]),
     ("iqlhip_train_steps_prepare", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float]),
     ("iqlhip_comm_unique_id", C.c_int, [C.c_void_p]),
     ("iqlhip_allreduce_init", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -119,6 +120,7 @@ SYMBOLS = [
                                     C.POINTER(C.c_int64), C.c_void_p]),
     ("iqlhip_debug_time_kernel", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.POINTER(C.c_float),
                                            C.c_void_p]),
+    ("iqlhip_debug_drain_spin", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     ("iqlhip_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("iqlhip_get_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 ]

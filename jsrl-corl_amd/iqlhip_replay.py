@@ -45,6 +45,9 @@ class ReplayBuffer:
         w = 2 * state_dim + action_dim + 2
         self._ld = hb.row_stride(state_dim, action_dim) if self._gpu else (w + 3) // 4 * 4
         self._rows = torch.zeros((buffer_size, self._ld), dtype=torch.float32, device=device)
+        # bumped by every method that writes rows: ImplicitQLearning.train_steps may start a call on rows its previous
+        # call staged ahead only while the buffer's contents are what they were then
+        self._writes = 0
 
     # ---- views with the reference's attribute names (iql.py:134-146) ------
     @property
@@ -78,6 +81,7 @@ class ReplayBuffer:
 
     def _write_rows(self, row0: int, s, a, r, ns, d) -> None:
         n = s.shape[0]
+        self._writes += 1
         if self._gpu:
             s, a, r, ns, d = (t.contiguous() for t in (s, a, r, ns, d))
             hb.check(hb.lib().iqlhip_rows_write(
@@ -135,6 +139,7 @@ class ReplayBuffer:
         s = torch.as_tensor(np.ascontiguousarray(std, dtype=np.float32).reshape(-1)).to(dev)
         if m.numel() != self._state_dim or s.numel() != self._state_dim:
             raise ValueError("mean / std must have state_dim entries")
+        self._writes += 1
         with torch.cuda.device(dev):
             hb.check(hb.lib().iqlhip_rows_normalize(self._rows.data_ptr(), self._ld, self._state_dim, self._action_dim,
                                                     0, self._size, m.data_ptr(), s.data_ptr(), self._stream()))
@@ -227,6 +232,7 @@ class ReplayBuffer:
                        done: bool):
         # one packed host row, one H2D copy (the reference issues five, iql.py:189-193)
         S, A = self._state_dim, self._action_dim
+        self._writes += 1
         if self._gpu:
             # pinned staging rows (ring of 4, each guarded by an event) and an asynchronous copy
             ring = getattr(self, "_row_ring", None)

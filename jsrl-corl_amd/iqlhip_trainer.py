@@ -86,6 +86,7 @@ class ImplicitQLearning:
         self._dp_rank = 0
         self._dp_exchange = None      # None | "rccl" | "p2p" (in-library) | "torch" (torch.distributed.all_reduce)
         self._table_cache = None
+        self._ts_token = None         # (buffer, its write count) of the last train_steps call
 
         self._ctx = None
         self._max_batch = 0
@@ -436,6 +437,7 @@ class ImplicitQLearning:
         row[2 * S + A] = np.float32(reward)
         row[2 * S + A + 1] = np.float32(done)
         pointer = buf._pointer
+        buf._writes += 1
         buf._pointer = (buf._pointer + 1) % buf._buffer_size
         buf._size = min(buf._size + 1, buf._buffer_size)
         idx = np.random.randint(0, buf._index_bound(), size=batch_size)
@@ -543,8 +545,15 @@ class ImplicitQLearning:
         return tab
 
     def _table_key(self, inv_batch: float):
-        return (float(inv_batch), tuple(sorted(self._adam_t.items())), self._schedule_state(),
-                tuple(sorted(self._current_lrs().items())), self._adam_hyper())
+        """Everything a precomputed scalar table depends on (plain attribute reads: this runs on the critical path of
+        every train_steps call, in front of the first launch)."""
+        t = self._adam_t
+        gv, gq, gp = (self.v_optimizer.param_groups[0], self.q_optimizer.param_groups[0],
+                      self.actor_optimizer.param_groups[0])
+        sch = self.actor_lr_schedule
+        return (inv_batch, t["v"], t["q"], t["pi"], gv["lr"], gq["lr"], gp["lr"],
+                None if sch is None else (sch.last_epoch, sch._step_count, sch.T_max),
+                gv["betas"], gv["eps"], gq["betas"], gq["eps"], gp["betas"], gp["eps"])
 
     def _scalar_table(self, k: int, inv_batch: float) -> np.ndarray:
         """The per-step scalars of the next k steps (float64 Adam bias corrections and cosine learning rates, cast to
@@ -556,8 +565,8 @@ class ImplicitQLearning:
         self._table_cache = None
         if cached is not None and cached[0] == key and cached[1].shape[0] >= k:
             # rows depend on the absolute step only: the first k rows of a longer look-ahead are this call's table
-            _, tab_all, lr_after, (e0, c0) = cached
-            tab = np.ascontiguousarray(tab_all[:k])
+            # (passed as it is: the library copies the first k rows before it returns)
+            _, tab, lr_after, (e0, c0) = cached
             self._commit_schedule((float(lr_after[k - 1]), None if e0 is None else e0 + k, None if c0 is None else c0 + k))
         else:
             lr_pi = self._advance_schedule(k)
@@ -576,8 +585,8 @@ class ImplicitQLearning:
         lr_used, _ = pk                     # lr_used[i] = learning rate step i uses = the rate AFTER i steps
         sch = self.actor_lr_schedule
         state0 = (None, None) if sch is None else (sch.last_epoch, sch._step_count)
-        self._table_cache = (self._table_key(inv_batch), self._build_table(k, inv_batch, self._adam_t, lr_used[:k]),
-                             lr_used[1:], state0)
+        tab = self._build_table(k, inv_batch, self._adam_t, lr_used[:k])       # (_adam_hyper inside: raises on optimizer
+        self._table_cache = (self._table_key(inv_batch), tab, lr_used[1:], state0)  #  settings the kernels do not implement)
 
     def _train_steps_args(self, replay_buffer, batch_size: int):
         self._prepare(batch_size)
@@ -615,14 +624,21 @@ class ImplicitQLearning:
         seed = dp.rank_seed(seed, rank)
         losses = np.empty((n_steps, 3), dtype=np.float32) if return_losses else None
         rows_ptr, ld, stream = replay_buffer._rows.data_ptr(), replay_buffer._ld, self._stream()
+        half = (batch_size + 1) // 2
         done = 0
         while done < n_steps:
             k = min(chunk, n_steps - done)
             tab = self._scalar_table(k, inv_batch)
-            hb.check(lib.iqlhip_train_steps(
-                self._ctx, rows_ptr, ld, size, batch_size,
-                tab.ctypes.data_as(C.POINTER(hb.StepScalars)), k,
-                seed, int(self.total_it) * ((batch_size + 1) // 2), stream))
+            # IQLHIP_TS_CONTINUE: nothing has written this buffer's rows since our previous call on it (the buffer
+            # counts its writes); the library itself checks that this call starts where that one's index stream ended
+            tok = (replay_buffer, replay_buffer._writes)
+            flags = hb.TS_CONTINUE if self._ts_token == tok else 0
+            rc = lib.iqlhip_train_steps(self._ctx, rows_ptr, ld, size, batch_size, tab.ctypes.data, k,
+                                        seed, self.total_it * half, flags, stream)
+            if rc:
+                self._ts_token = None
+                hb.check(rc)
+            self._ts_token = tok
             self.total_it += k
             done += k
             # the GPU is busy with these k steps: compute the scalars of the next k now
