@@ -41,7 +41,8 @@ enum {
   IQLHIP_EINVAL = -1,    /* bad argument (maps to ValueError in the shim) */
   IQLHIP_EHIP = -2,      /* a HIP runtime call failed (RuntimeError) */
   IQLHIP_ENOTBOUND = -3, /* step before iqlhip_bind */
-  IQLHIP_EUNSUPPORTED = -4 /* dims the kernels are not built for (NotImplementedError) */
+  IQLHIP_EUNSUPPORTED = -4, /* dims the kernels are not built for (NotImplementedError) */
+  IQLHIP_EINDEX = -5     /* a row index outside the buffer (IndexError, like the reference's tensor indexing iql.py:173-177) */
 };
 
 enum { IQLHIP_NET_V = 0, IQLHIP_NET_Q1 = 1, IQLHIP_NET_Q2 = 2, IQLHIP_NET_PI = 3 };
@@ -193,8 +194,10 @@ int iqlhip_train_steps(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int64
 
 /* Capture, instantiate, upload AND rehearse (arenas saved and restored) every chunk graph iqlhip_train_steps replays for
  * this (buffer, batch_rows, inv_batch) — and, with an exchange attached, this exchange mode — so that no later
- * iqlhip_train_steps call pays for a capture or a first replay (bench.py calls it before its timed region). */
-int iqlhip_train_steps_prepare(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int32_t batch_rows, float inv_batch);
+ * iqlhip_train_steps call pays for a capture or a first replay (bench.py calls it before its timed region).  The
+ * rehearsal replays run on `stream` (pass the stream the later calls will use); synchronous. */
+int iqlhip_train_steps_prepare(iqlhip_ctx* ctx, const float* rows_dev, int64_t ld, int32_t batch_rows, float inv_batch,
+                               void* stream);
 
 /* ---- data-parallel gradient exchange (the reference has no multi-device code) ----------------
  * One process per GPU.  With an exchange attached, iqlhip_step and iqlhip_train_steps run, per step:
@@ -239,22 +242,26 @@ int64_t iqlhip_row_stride(int32_t state_dim, int32_t action_dim);
 int iqlhip_rows_write(float* rows_dev, int64_t ld, int32_t state_dim, int32_t action_dim, int64_t row0, int64_t n,
                       const float* s_dev, const float* a_dev, const float* r_dev, const float* ns_dev,
                       const float* d_dev, void* stream);
-/* ReplayBuffer.sample's five advanced-index gathers (iql.py:173-177) in one launch. */
-int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int32_t state_dim, int32_t action_dim,
+/* ReplayBuffer.sample's five advanced-index gathers (iql.py:173-177) in one launch.  n_rows = rows the buffer holds
+ * (its capacity): the reference's indexing raises IndexError for an index outside the tensors; the entry points that
+ * see the indices on the host return IQLHIP_EINDEX before anything is launched, the ones that take device indices never
+ * dereference such an index (its output row is filled with NaN instead of faulting the GPU) — a caller that wants the
+ * exception checks device indices itself, as the Python shim's ReplayBuffer.gather does. */
+int iqlhip_rows_gather(const float* rows_dev, int64_t ld, int64_t n_rows, int32_t state_dim, int32_t action_dim,
                        const int64_t* idx_dev, int64_t n, float* s_dev, float* a_dev, float* r_dev, float* ns_dev,
                        float* d_dev, void* stream);
 /* The same sample as whole packed rows: out[i] = rows[idx[i]] (one coalesced row copy per sample).  A batch whose
  * five pointers are the packed offsets of such a block (a = s + S, s' = s + S + A, r = s + 2S + A, d = r + 1, all
  * strides = iqlhip_row_stride, 16-byte aligned) is consumed IN PLACE by iqlhip_step / iqlhip_forward_backward. */
-int iqlhip_rows_gather_packed(const float* rows_dev, int64_t ld, const int64_t* idx_dev, int64_t n,
+int iqlhip_rows_gather_packed(const float* rows_dev, int64_t ld, int64_t n_rows, const int64_t* idx_dev, int64_t n,
                               float* out_rows_dev, void* stream);
 /* ... with the indices still in (pinned) host memory, as np.random.randint leaves them (iql.py:172): copies them to
  * idx_scratch_dev on `stream`, then gathers.  idx_host must stay untouched until that copy has run. */
-int iqlhip_rows_gather_packed_h(const float* rows_dev, int64_t ld, const int64_t* idx_host, int64_t* idx_scratch_dev,
-                                int64_t n, float* out_rows_dev, void* stream);
+int iqlhip_rows_gather_packed_h(const float* rows_dev, int64_t ld, int64_t n_rows, const int64_t* idx_host,
+                                int64_t* idx_scratch_dev, int64_t n, float* out_rows_dev, void* stream);
 /* ... or in ordinary host memory: the library stages them through its own pinned ring (event-guarded) — the whole
  * device side of ReplayBuffer.sample(batch_size) after the np.random.randint draw, in one call. */
-int iqlhip_rows_sample_packed(const float* rows_dev, int64_t ld, const int64_t* idx_host, int64_t n,
+int iqlhip_rows_sample_packed(const float* rows_dev, int64_t ld, int64_t n_rows, const int64_t* idx_host, int64_t n,
                               float* out_rows_dev, void* stream);
 /* ---- dataset ingest on the device -------------------------------------------------------------
  * compute_mean_std (algorithms/finetune/iql.py:77-80): mean[c] = mean_r x[r][c], std[c] = sqrt(mean_r (x - mean)^2) + eps

@@ -206,13 +206,24 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
 
 // ---------------------------------------------------------------------------
 // rows[idx[r]] -> xb[r], r < n: one float4 per thread-iteration (rows are 16-B aligned, ld % 4 == 0)
+// n_rows > 0: an index outside [0, n_rows) is never dereferenced — its output row is filled with NaN instead (the
+// reference's torch indexing raises IndexError, iql.py:173-177; the Python shim raises it on the host before the
+// launch — this guard only makes sure that a caller of the C ABI cannot fault the GPU with a bad index).
 __device__ __forceinline__ void gather_rows_flat(const float* rows, long long ld, const long long* idx, float* xb,
-                                                 int n, int first, int stride) {
+                                                 int n, int first, int stride, long long n_rows = 0) {
   const int q = (int)(ld >> 2);
   const int total = n * q;
   for (int e = first; e < total; e += stride) {
     const int r = e / q, c4 = e - r * q;
-    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = *(const f32x4*)(rows + idx[r] * ld + 4 * c4);
+    const long long i = idx[r];
+    f32x4 v;
+    if (n_rows > 0 && (i < 0 || i >= n_rows)) {
+      const float nanv = __builtin_nanf("");
+      v = (f32x4){nanv, nanv, nanv, nanv};
+    } else {
+      v = *(const f32x4*)(rows + i * ld + 4 * c4);
+    }
+    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = v;
   }
 }
 
@@ -1985,8 +1996,8 @@ __global__ void iql_debug_flag_kernel(unsigned long long* flag, unsigned long lo
 }
 
 __global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long long ld, const long long* idx,
-                                                         float* xb, int n) {
-  gather_rows_flat(rows, ld, idx, xb, n, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+                                                         float* xb, int n, long long n_rows) {
+  gather_rows_flat(rows, ld, idx, xb, n, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, n_rows);
 }
 
 // 16-byte accesses at SYSTEM scope (sc0 sc1): the load misses every cache level that is not coherent with another
@@ -2304,15 +2315,17 @@ __global__ void iql_rows_write_kernel(float* rows, long long ld, int S, int A, l
   }
 }
 
-__global__ void iql_rows_gather_kernel(const float* rows, long long ld, int S, int A, const long long* idx,
-                                       long long n, float* s, float* a, float* r, float* ns, float* d) {
+__global__ void iql_rows_gather_kernel(const float* rows, long long ld, long long n_rows, int S, int A,
+                                       const long long* idx, long long n, float* s, float* a, float* r, float* ns,
+                                       float* d) {
   const int W = 2 * S + A + 2;
   const long long total = n * W;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const long long i = e / W;
     const int c = (int)(e - i * W);
-    const float v = rows[idx[i] * ld + c];
+    const long long ri = idx[i];
+    const float v = (n_rows > 0 && (ri < 0 || ri >= n_rows)) ? __builtin_nanf("") : rows[ri * ld + c];     // (see gather_rows_flat)
     if (c < S) s[i * S + c] = v;
     else if (c < S + A) a[i * A + (c - S)] = v;
     else if (c < 2 * S + A) ns[i * S + (c - S - A)] = v;

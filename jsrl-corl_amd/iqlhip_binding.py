@@ -24,7 +24,7 @@ TS_CONTINUE = 1
 NET_V, NET_Q1, NET_Q2, NET_PI = 0, 1, 2, 3
 POLICY_GAUSSIAN, POLICY_DETERMINISTIC = 0, 1
 
-E_INVAL, E_HIP, E_NOTBOUND, E_UNSUPPORTED = -1, -2, -3, -4
+E_INVAL, E_HIP, E_NOTBOUND, E_UNSUPPORTED, E_INDEX = -1, -2, -3, -4, -5
 
 
 class Dims(C.Structure):
@@ -87,7 +87,7 @@ SYMBOLS = [
     ("iqlhip_grad_words", C.c_int64, [C.c_void_p]),
     ("iqlhip_train_steps", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                      C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p]),
-    ("iqlhip_train_steps_prepare", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float]),
+    ("iqlhip_train_steps_prepare", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     ("iqlhip_comm_unique_id", C.c_int, [C.c_void_p]),
     ("iqlhip_allreduce_init", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     ("iqlhip_p2p_export", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -100,17 +100,17 @@ SYMBOLS = [
     ("iqlhip_row_stride", C.c_int64, [C.c_int32, C.c_int32]),
     ("iqlhip_rows_write", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    ("iqlhip_rows_gather", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+    ("iqlhip_rows_gather", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("iqlhip_actor_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_float,
                                        C.c_void_p, C.c_int64, C.c_void_p]),
-    ("iqlhip_rows_gather_packed", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("iqlhip_rows_gather_packed", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("iqlhip_actor_sample", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float, C.c_void_p,
                                       C.c_int64, C.c_void_p]),
     ("iqlhip_stream_synchronize", C.c_int, [C.c_void_p]),
-    ("iqlhip_rows_gather_packed_h", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+    ("iqlhip_rows_gather_packed_h", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                               C.c_void_p]),
-    ("iqlhip_rows_sample_packed", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("iqlhip_rows_sample_packed", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("iqlhip_cols_mean_std", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     ("iqlhip_rows_normalize", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p,
@@ -161,6 +161,8 @@ def check(rc: int) -> None:
         raise ValueError(msg)
     if rc == E_UNSUPPORTED:
         raise NotImplementedError(msg)
+    if rc == E_INDEX:
+        raise IndexError(msg)
     raise RuntimeError(msg)
 
 

@@ -173,6 +173,23 @@ class ReplayBuffer:
                 done.record()
         return dev_idx
 
+    def _checked_indices(self, idx: torch.Tensor) -> torch.Tensor:
+        """The reference's `self._states[indices]` (iql.py:173-177) raises IndexError for an index outside
+        [-buffer_size, buffer_size) and wraps negative ones; a gather kernel would read out of bounds.  Checked on the
+        host before anything is launched (one small device reduction + read-back when the indices live on the GPU)."""
+        cap = self._buffer_size
+        if idx.dtype != torch.int64:
+            idx = idx.to(torch.int64)
+        if idx.numel() == 0:
+            return idx
+        lo, hi = (int(v) for v in torch.stack((idx.min(), idx.max())).tolist())
+        if lo < -cap or hi >= cap:
+            bad = hi if hi >= cap else lo
+            raise IndexError(f"index {bad} is out of bounds for dimension 0 with size {cap}")
+        if lo < 0:
+            idx = torch.where(idx < 0, idx + cap, idx)
+        return idx
+
     def gather(self, idx: torch.Tensor) -> TensorBatch:
         n = idx.shape[0]
         S, A = self._state_dim, self._action_dim
@@ -184,8 +201,9 @@ class ReplayBuffer:
         # one coalesced copy of whole packed rows; the five tensors of the reference's contract are views of that
         # block (shapes as in iql.py:173-177, row stride = the packed stride) — ImplicitQLearning.train() hands
         # such a block to the library in place, with no re-packing
+        idx = self._checked_indices(idx.to(self._rows.device))
         block = torch.empty((n, self._ld), dtype=torch.float32, device=self._rows.device)
-        hb.check(hb.lib().iqlhip_rows_gather_packed(self._rows.data_ptr(), self._ld, idx.data_ptr(), n,
+        hb.check(hb.lib().iqlhip_rows_gather_packed(self._rows.data_ptr(), self._ld, self._buffer_size, idx.data_ptr(), n,
                                                     block.data_ptr(), self._stream()))
         return [block[:, :S], block[:, S: S + A], block[:, 2 * S + A: 2 * S + A + 1], block[:, S + A: 2 * S + A],
                 block[:, 2 * S + A + 1: 2 * S + A + 2]]
@@ -195,13 +213,14 @@ class ReplayBuffer:
         n = idx.shape[0]
         S, A = self._state_dim, self._action_dim
         dev = self._rows.device
+        idx = self._checked_indices(idx.to(dev))
         out = [torch.empty((n, S), dtype=torch.float32, device=dev),
                torch.empty((n, A), dtype=torch.float32, device=dev),
                torch.empty((n, 1), dtype=torch.float32, device=dev),
                torch.empty((n, S), dtype=torch.float32, device=dev),
                torch.empty((n, 1), dtype=torch.float32, device=dev)]
         hb.check(hb.lib().iqlhip_rows_gather(
-            self._rows.data_ptr(), self._ld, S, A, idx.data_ptr(), n,
+            self._rows.data_ptr(), self._ld, self._buffer_size, S, A, idx.data_ptr(), n,
             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(),
             self._stream()))
         return out
@@ -219,12 +238,13 @@ class ReplayBuffer:
         dev = self._rows.device
         block = torch.empty((batch_size, self._ld), dtype=torch.float32, device=dev)
         if torch.cuda.current_device() == dev.index:
-            hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows.data_ptr(), self._ld, indices.ctypes.data,
-                                                        batch_size, block.data_ptr(), self._stream()))
+            hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows.data_ptr(), self._ld, self._buffer_size,
+                                                        indices.ctypes.data, batch_size, block.data_ptr(), self._stream()))
         else:
             with torch.cuda.device(dev):
-                hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows.data_ptr(), self._ld, indices.ctypes.data,
-                                                            batch_size, block.data_ptr(), self._stream()))
+                hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows.data_ptr(), self._ld, self._buffer_size,
+                                                            indices.ctypes.data, batch_size, block.data_ptr(),
+                                                            self._stream()))
         return [block[:, :S], block[:, S: S + A], block[:, 2 * S + A: 2 * S + A + 1], block[:, S + A: 2 * S + A],
                 block[:, 2 * S + A + 1: 2 * S + A + 2]]
 

@@ -604,7 +604,8 @@ class ImplicitQLearning:
         train_steps call pays for it (it is captured lazily otherwise, by the first call of >= 64 steps)."""
         _, inv_batch = self._train_steps_args(replay_buffer, batch_size)
         hb.check(hb.lib().iqlhip_train_steps_prepare(self._ctx, replay_buffer._rows.data_ptr(), replay_buffer._ld,
-                                                      batch_size, inv_batch))
+                                                      batch_size, inv_batch, self._stream()))
+        self._ts_token = None
 
     def train_steps(self, replay_buffer, n_steps: int, batch_size: int, seed: int = 0,
                     return_losses: bool = True, chunk: int = K_MAX) -> Optional[np.ndarray]:

@@ -113,7 +113,7 @@ def test_online_step_equals_add_sample_train():
         for k in pa[n]:
             assert np.array_equal(pa[n][k], pb[n][k]), (n, k)
     assert tr_b.total_it == 130 and tr_a.actor_optimizer.param_groups[0]["lr"] == tr_b.actor_optimizer.param_groups[0]["lr"]
-    with pytest.raises(ValueError):      # an index outside the ring is refused on the host (a gather would fault)
+    with pytest.raises(IndexError):      # an index outside the ring is refused on the host like the reference's indexing (a gather would fault)
         import ctypes as C
         import iqlhip_binding as hb
         bad = np.full(B, cap, dtype=np.int64)

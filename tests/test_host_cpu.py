@@ -70,19 +70,32 @@ def test_argument_validation_precedes_any_device_work():
     lib = hb.lib()
     # NULL pointers / bad geometry -> IQLHIP_EINVAL -> ValueError
     for call in (
-        lambda: lib.iqlhip_rows_gather_packed(None, 44, None, 4, None, None),
-        lambda: lib.iqlhip_rows_gather_packed(16, 43, 16, 4, 16, None),           # stride not a multiple of 4 floats
-        lambda: lib.iqlhip_rows_gather_packed(8, 44, 16, 4, 16, None),            # rows not 16-byte aligned
-        lambda: lib.iqlhip_rows_gather_packed_h(16, 44, None, None, 4, 16, None),
+        lambda: lib.iqlhip_rows_gather_packed(None, 44, 100, None, 4, None, None),
+        lambda: lib.iqlhip_rows_gather_packed(16, 43, 100, 16, 4, 16, None),      # stride not a multiple of 4 floats
+        lambda: lib.iqlhip_rows_gather_packed(8, 44, 100, 16, 4, 16, None),       # rows not 16-byte aligned
+        lambda: lib.iqlhip_rows_gather_packed(16, 44, 0, 16, 4, 16, None),        # a buffer of no rows
+        lambda: lib.iqlhip_rows_gather_packed_h(16, 44, 100, None, None, 4, 16, None),
         lambda: lib.iqlhip_actor_forward(None, None, 17, 1, None, 6, 1.0, None, 6, None),
-        lambda: lib.iqlhip_rows_gather(None, 44, 17, 6, None, 4, None, None, None, None, None, None),
+        lambda: lib.iqlhip_rows_gather(None, 44, 100, 17, 6, None, 4, None, None, None, None, None, None),
         lambda: lib.iqlhip_draw_indices(None, 4, 10, 0, 0, None),
     ):
         with pytest.raises(ValueError):
             hb.check(call())
     assert "argument" in hb.last_error().lower() or hb.last_error()
     # zero rows are a no-op, not an error
-    hb.check(lib.iqlhip_rows_gather_packed(16, 44, 16, 0, 16, None))
+    hb.check(lib.iqlhip_rows_gather_packed(16, 44, 100, 16, 0, 16, None))
+    # a host-visible row index outside the buffer -> IQLHIP_EINDEX -> IndexError (the reference's tensor indexing,
+    # iql.py:173-177), before any launch: the entry points that receive the indices in host memory
+    import ctypes as C
+    bad = (C.c_int64 * 4)(0, 5, 100, 7)
+    neg = (C.c_int64 * 2)(3, -1)
+    for call in (
+        lambda: lib.iqlhip_rows_sample_packed(16, 44, 100, C.addressof(bad), 4, 16, None),
+        lambda: lib.iqlhip_rows_gather_packed_h(16, 44, 100, C.addressof(neg), 16, 2, 16, None),
+    ):
+        with pytest.raises(IndexError):
+            hb.check(call())
+    assert "out of bounds" in hb.last_error()
 
 
 # ---------------------------------------------------------------- replay buffer host logic
