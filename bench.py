@@ -45,7 +45,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 HID = 256
 ROWS_1GPU = 1_000_000          # BASELINE.json configs[1]
 ROWS_DP = 10_000_000           # BASELINE.json configs[3]
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+# rocprofv3 PMC passes of this bench command, collected by tools/profile_round.sh and committed (the newest round's file)
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_summary.json", "r02_pmc_summary.json")]
 
 
 def flops(S, A, B):
@@ -71,8 +72,12 @@ def parse_args(argv=None):
                     help="f32 = the parity path (headline); bf16 = bf16 operands / fp32 accumulate in the layer and weight-gradient products")
     ap.add_argument("--exchange", choices=("auto", "rccl", "p2p"), default="auto",
                     help="N > 1: gradient exchange (auto = time both in the warm-up, keep the faster valid one)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed repeats of --steps, the MEDIAN is reported (default: 5 when --steps >= 1000, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--cpu-seconds", type=float, default=14.0,
+                    help="budget per thread setting of the cpu_baseline leg (after 200 warm-up steps; it stops at 2 000 steps)")
+    ap.add_argument("--timeout", type=float, default=540.0, help="self-launched ranks: overall wall-clock bound in seconds")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="print the rank fan-out this invocation would start (JSON) and exit; touches no GPU")
     ap.add_argument("--master-port", type=int, default=0)
@@ -94,7 +99,9 @@ def launch_plan(args, argv):
 
 def spawn_ranks(args, argv) -> int:
     """Parent of a self-launched multi-GPU run.  It has not touched the GPU (no torch import, no HIP call) and never
-    will: the ranks are fresh child processes; rank 0's stdout (the JSON line) is passed through."""
+    will: the ranks are fresh child processes; rank 0's stdout (the JSON line) is passed through.  All children are
+    polled together: the first one that exits non-zero (out of memory on the 10 M-row buffer, a failed attach) takes
+    the others down at once instead of leaving them in a collective until its timeout; the whole run is bounded."""
     plan = launch_plan(args, argv)
     procs = []
     for item in plan:
@@ -102,14 +109,37 @@ def spawn_ranks(args, argv) -> int:
         env.update(item["env"])
         out = None if item["rank"] == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen(item["cmd"], env=env, stdout=out))
+    return wait_ranks(procs, args.timeout)
+
+
+def wait_ranks(procs, timeout_s: float, poll_s: float = 0.05) -> int:
+    """0 when every child exited 0; otherwise the first failure's code (124 on the overall timeout) after the rest has
+    been terminated (then killed)."""
+    deadline = time.monotonic() + timeout_s
     rc = 0
+    while True:
+        codes = [pr.poll() for pr in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        if time.monotonic() > deadline:
+            sys.stderr.write(f"bench.py: ranks still running after {timeout_s:.0f} s, terminating them\n")
+            rc = 124
+            break
+        time.sleep(poll_s)
     for pr in procs:
-        pr.wait()
-        rc = rc or pr.returncode
-    if rc:                                            # one rank failed: do not leave the others waiting in a collective
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
+        if pr.poll() is None:
+            pr.terminate()
+    t_kill = time.monotonic() + 5.0
+    for pr in procs:
+        while pr.poll() is None and time.monotonic() < t_kill:
+            time.sleep(poll_s)
+        if pr.poll() is None:
+            pr.kill()
+            pr.wait()
     return rc
 
 
@@ -165,13 +195,10 @@ def run_rank(args, world: int) -> int:
     torch.cuda.set_device(dev_index)
 
     # ---- synthetic HBM-resident buffer + nets (seed 0; every rank holds the same replicated buffer)
-    import contextlib
-    import io
+    # (rows are generated on the device, identically on every rank: Philox fill kernel with synth.py's distributions —
+    #  at 10 M rows the host generator cost every rank ~30 s of numpy and a 1.7 GB upload)
     buf = iql.ReplayBuffer(S, A, rows, dev)
-    data = synth.synth_transitions(rows, S, A, seed=0)
-    with contextlib.redirect_stdout(io.StringIO()):
-        buf.load_d4rl_dataset(data)
-    del data
+    buf.fill_synthetic(rows, seed=0)
     torch.manual_seed(0)
     qf, vf, actor = iql.TwinQ(S, A).to(dev), iql.ValueFunction(S).to(dev), iql.GaussianPolicy(S, A, 1.0).to(dev)
     tr = iql.ImplicitQLearning(
@@ -222,7 +249,7 @@ def run_rank(args, world: int) -> int:
         return bool(torch.equal(lo, hi)) and int(bad.item()) == 0
 
     # ---- exchange (N > 1): attach, pre-capture, pick
-    exchange, probe = None, {}
+    exchange, probe, why = None, {}, None
     warm = args.warmup
     if world > 1:
         want = args.exchange
@@ -233,39 +260,59 @@ def run_rank(args, world: int) -> int:
                 if getattr(tr, attr, None):              # that exchange could not be attached on some rank
                     modes.remove(m)
                     probe[m] = {"unavailable": getattr(tr, attr)}
-            if not modes:                                # (enable_data_parallel fell back to torch.distributed)
-                eager_dp[0] = True
         for m in modes:
             tr.select_exchange(m)
             tr.prepare_train_steps(buf, B)
+
+        def probe_mode(m, n):
+            """n steps on exchange m: rate, and whether it left the replicas bit-identical with no wait timed out.  A
+            probe that did not is undone: rank 0's state is broadcast again, the timeout word cleared."""
+            tr.select_exchange(m)
+            t = timed(n)
+            if os.environ.get("IQLHIP_BENCH_BREAK_PROBE") == m and rank == world - 1:
+                tr._params_arena[:4] += 1e-3      # test hook: this probe leaves the replicas REALLY diverged
+            ok = replicas_equal()
+            probe[m] = {"steps_per_s": round(n * world / t, 1), "replicas_equal": ok}
+            if not ok:
+                tr.resync_replicas()
+                probe[m]["resynced"] = True
+            return ok
+
         if want == "auto":
-            # the warm-up steps are split between the two exchanges and timed; the faster one that kept the replicas
-            # bit-identical runs the timed region.  (Too few warm-up steps to tell: RCCL, the vendor's collective.)
-            half = warm // 2
-            if not modes:
-                exchange = "torch"
+            # the warm-up steps are split between the attached exchanges and timed; the fastest one that kept the
+            # replicas bit-identical runs the timed region; with none left: the eager torch.distributed exchange
+            share = max(8, warm // 2) if len(modes) > 1 else 0
+            if len(modes) > 1:
+                ok = [m for m in modes if probe_mode(m, share)]
+                warm = max(0, warm - share * len(modes))
+                if ok:
+                    exchange = max(ok, key=lambda m: probe[m]["steps_per_s"])
+                    why = f"fastest of the exchanges that kept the replicas identical in a {share}-step probe each: {ok}"
             elif len(modes) == 1:
-                exchange = modes[0]
-            elif half >= 8:
-                for m in modes:
-                    tr.select_exchange(m)
-                    t = timed(half)
-                    probe[m] = {"steps_per_s": round(half * world / t, 1), "replicas_equal": replicas_equal()}
-                warm -= 2 * half
-                ok = [m for m in modes if probe[m].get("replicas_equal")]
-                exchange = max(ok, key=lambda m: probe[m]["steps_per_s"]) if ok else "rccl"
-            else:
-                exchange = "rccl"
-            if modes:
-                tr.select_exchange(exchange)
+                if probe_mode(modes[0], max(8, min(warm, 64))):
+                    exchange = modes[0]
+                    why = "the only in-library exchange that could be attached (see exchange_probe) and it kept the replicas identical"
+            if exchange is None:
+                exchange = "torch"
+                why = "no in-library exchange is usable here (see exchange_probe): eager torch.distributed all-reduce per step"
         else:
             exchange = want
+            why = "selected with --exchange"
+            if not probe_mode(want, max(8, min(warm, 64))):
+                raise RuntimeError(f"--exchange {want}: the replicas diverged or a peer wait timed out in the probe: {probe}")
+        if exchange == "torch":
+            eager_dp[0] = True
+            tr.select_exchange("torch")
+        else:
+            tr.select_exchange(exchange)
     else:
         tr.prepare_train_steps(buf, B)       # capture + instantiate + upload the chunk graph: never in the timed region
 
     if warm > 0:
         run(warm)
-    dt = timed(args.steps)
+    repeats = args.repeats if args.repeats > 0 else (5 if args.steps >= 1000 else 1)
+    dts = [timed(args.steps) for _ in range(repeats)]      # EXACTLY --steps per timed region; the median region is reported
+    dt = sorted(dts)[len(dts) // 2]
 
     # sanity: the run trained (losses finite), replicas still identical
     log = tr.train(buf.sample(B)) if world == 1 else tr.train_on_buffer(buf, B, seed=1, sync=True)
@@ -287,23 +334,38 @@ def run_rank(args, world: int) -> int:
         # HBM-side bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950
         # correction; tools/pmc_traffic.py).  Only valid for the default workload.
-        traffic, mfma_util = None, None
-        if os.path.exists(PMC_SUMMARY) and (S, A, B) == (17, 6, 256) and args.precision == "f32":
-            with open(PMC_SUMMARY) as fh:
-                for name, rec in json.load(fh).items():
-                    if "iql_bwd_kernel" in name:
-                        traffic = rec.get("hbm_bytes_per_launch_corrected")
-                        mfma_util = rec.get("mfma_util")      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)
-        peak = PEAK_F32_MFMA_TFLOPS     # (bf16 mode keeps the heads and the policy's dH1 on fp32 MFMAs; priced against fp32)
-        roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": peak,
+        traffic, mfma_util, pmc_src = None, None, None
+        if (S, A, B) == (17, 6, 256) and args.precision == "f32":
+            for path in PMC_SUMMARIES:
+                if not os.path.exists(path):
+                    continue
+                with open(path) as fh:
+                    for name, rec in json.load(fh).items():
+                        if "iql_bwd_kernel" in name:
+                            traffic = rec.get("hbm_bytes_per_launch_corrected")
+                            mfma_util = rec.get("mfma_util")      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)
+                            pmc_src = os.path.relpath(path, ROOT)
+                if pmc_src:
+                    break
+        # f32: the fp32-MFMA peak.  bf16 mode: the share of the launch's FLOPs that runs on v_mfma_f32_*_bf16 (layer 0 /
+        # layer 1 forward, dW1, dH0, dW0) is priced against the bf16 peak, the rest (heads, the policy's dH1) against fp32
+        peak = PEAK_F32_MFMA_TFLOPS
+        if args.precision == "bf16":
+            fp32_share = (2 * B * HID * (3 + 2 * A) * 2) / f_bwd            # dY.W2 and dW2 of the four heads
+            peak = 1.0 / (fp32_share / PEAK_F32_MFMA_TFLOPS + (1.0 - fp32_share) / PEAK_BF16_MFMA_TFLOPS)
+        roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None if traffic is None else round(traffic),
+                "traffic_source": None if traffic is None else f"{pmc_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE; not measured in this run)",
                 "mfma_util_pmc": None if mfma_util is None else round(mfma_util, 4),
+                "mfma_util_source": None if mfma_util is None else pmc_src,
                 "flops_per_launch": f_bwd, "avg_launch_us": round(t_bwd, 3),
+                "avg_launch_us_source": "HIP events around 500 back-to-back launches of the kernel, in this run",
                 "kernel_us": {"iql_fwd_kernel": round(t_fwd, 3), "iql_bwd_kernel": round(t_bwd, 3),
                               "iql_update_kernel": round(t_upd, 3)},
                 "step_flops": f_fwd + f_bwd,
-                "step_frac_of_peak": round((f_fwd + f_bwd) * args.steps / dt / 1e12 / peak, 4)}
+                # the same fraction for the whole step, from the TIMED region (all launches, gaps and fixed costs included)
+                "frac_step": round((f_fwd + f_bwd) * args.steps / dt / 1e12 / peak, 4)}
 
     if rank != 0:
         if world > 1:
@@ -315,10 +377,16 @@ def run_rank(args, world: int) -> int:
     cfg = {"workload": f"IQL step on synthetic buffer (obs={S}, act={A}, {rows} rows), batch={B} per GPU",
            "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
            "global_steps_per_s": round(args.steps / dt, 1)}
+    if repeats > 1:
+        cfg["timed_regions_ms"] = [round(x * 1e3, 3) for x in dts]
+        cfg["reported"] = f"median of {repeats} timed regions of {args.steps} steps"
     if world > 1:
         cfg["exchange"] = exchange
+        cfg["exchange_why"] = why
         if probe:
             cfg["exchange_probe"] = probe
+        cfg["multi_gpu_note"] = ("ranks on distinct GPUs" if torch.cuda.device_count() >= world
+                                 else f"REHEARSAL: {world} ranks share {torch.cuda.device_count()} GPU(s) — not a scaling measurement")
     out = {
         "metric": f"IQL gradient-steps/sec at batch={B} (D4RL obs/act dims)",      # BASELINE.json's metric at the default B = 256
         "value": round(value, 1),
@@ -350,12 +418,13 @@ def run_rank(args, world: int) -> int:
         for thr in sorted({1, thr_many}):
             sys.stderr.write(f"bench.py: cpu_baseline on {thr} thread(s), {args.cpu_seconds:.0f} s ...\n")
             sys.stderr.flush()
-            sps, n, el = port.time_cpu_steps(S, A, B, cpu_rows, seconds_budget=args.cpu_seconds, threads=thr)
+            sps, n, el = port.time_cpu_steps(S, A, B, cpu_rows, seconds_budget=args.cpu_seconds, threads=thr,
+                                             warmup=200, max_steps=2000)
             runs.append((sps, thr, n, el))
         best, cores, _, _ = max(runs)
         out["cpu_baseline"] = {
             "value": round(best, 2), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"PyTorch-CPU port of the reference step (oracle/iql_torch_port.py), same S/A/B, {cpu_rows}-row buffer: "
+            "sample": f"PyTorch-CPU port of the reference step (oracle/iql_torch_port.py), same S/A/B, {cpu_rows}-row buffer, 200 warm-up steps then <= 2000 steps or {args.cpu_seconds:.0f} s per thread setting: "
                       + "; ".join(f"{n} steps in {el:.1f}s @{thr} thread(s) = {sps:.1f}/s" for sps, thr, n, el in runs)
                       + f"; torch {torch.__version__}; the process may run on {ncpu} host cpus, of which a 1-GPU box grants 16"}
         out["speedup_vs_cpu"] = round(value / best, 1)

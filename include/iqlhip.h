@@ -42,7 +42,8 @@ enum {
   IQLHIP_EHIP = -2,      /* a HIP runtime call failed (RuntimeError) */
   IQLHIP_ENOTBOUND = -3, /* step before iqlhip_bind */
   IQLHIP_EUNSUPPORTED = -4, /* dims the kernels are not built for (NotImplementedError) */
-  IQLHIP_EINDEX = -5     /* a row index outside the buffer (IndexError, like the reference's tensor indexing iql.py:173-177) */
+  IQLHIP_EINDEX = -5,    /* a row index outside the buffer (IndexError, like the reference's tensor indexing iql.py:173-177) */
+  IQLHIP_EEXCHANGE = -6  /* a peer of the P2P gradient exchange did not arrive in time: replicas out of sync (RuntimeError) */
 };
 
 enum { IQLHIP_NET_V = 0, IQLHIP_NET_Q1 = 1, IQLHIP_NET_Q2 = 2, IQLHIP_NET_PI = 3 };
@@ -227,6 +228,10 @@ int iqlhip_xch_select(iqlhip_ctx* ctx, int mode);
 /* status[0] = mode in use, status[1] = first step at which a P2P wait timed out (0 = never), status[2] = steps
  * exchanged so far.  Synchronises `stream`. */
 int iqlhip_xch_status(iqlhip_ctx* ctx, int64_t status[3], void* stream);
+/* Forget a recorded P2P wait timeout (status[1] back to 0) once the caller has re-synchronised the replicas and
+ * selected another exchange.  Until then iqlhip_read_losses / iqlhip_read_loss_ring / iqlhip_online_step — the entry
+ * points that synchronise — return IQLHIP_EEXCHANGE; fully asynchronous callers poll iqlhip_xch_status. */
+int iqlhip_xch_clear_status(iqlhip_ctx* ctx, void* stream);
 /* Release communicator / peer mappings (also done by iqlhip_destroy). */
 int iqlhip_xch_shutdown(iqlhip_ctx* ctx);
 
@@ -242,6 +247,12 @@ int64_t iqlhip_row_stride(int32_t state_dim, int32_t action_dim);
 int iqlhip_rows_write(float* rows_dev, int64_t ld, int32_t state_dim, int32_t action_dim, int64_t row0, int64_t n,
                       const float* s_dev, const float* a_dev, const float* r_dev, const float* ns_dev,
                       const float* d_dev, void* stream);
+/* Synthetic D4RL-shaped rows written where they live (bench data of SURVEY §8d's distributions: obs / next_obs ~ N(0,1),
+ * actions ~ U(-1,1) * 0.999, rewards ~ N(0,1) or the antmaze flavour {-1, 0}, dones ~ Bernoulli(p_done); Philox4x32-10
+ * keyed by `seed`, counter = element number, so every rank of a data-parallel run fills identical rows without a
+ * host-side generator or an upload).  Replaces nothing in the reference (its data come from d4rl.qlearning_dataset). */
+int iqlhip_rows_fill_synth(float* rows_dev, int64_t ld, int32_t state_dim, int32_t action_dim, int64_t row0, int64_t n,
+                           uint64_t seed, float p_done, int32_t antmaze_rewards, void* stream);
 /* ReplayBuffer.sample's five advanced-index gathers (iql.py:173-177) in one launch.  n_rows = rows the buffer holds
  * (its capacity): the reference's indexing raises IndexError for an index outside the tensors; the entry points that
  * see the indices on the host return IQLHIP_EINDEX before anything is launched, the ones that take device indices never

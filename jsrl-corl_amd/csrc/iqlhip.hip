@@ -177,6 +177,7 @@ struct iqlhip_ctx {
   char* peer_blk[IQLHIP_MAX_WORLD] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool p2p_attached = false;
   unsigned long long* xstatus = nullptr;   // device: [0] first timed-out step, [1] spare
+  unsigned long long* xstatus_host = nullptr;   // pinned landing pad of the status words
   unsigned long long xstep = 0;            // steps exchanged so far (the P2P flags count them)
   unsigned long long xtimeout_ticks = 500000000ull;   // 5 s of the 100 MHz wall clock
   // timing
@@ -296,6 +297,8 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   HIPCHK(hipMemset(c->hdr, 0, HDR_WORDS * sizeof(unsigned long long)));
   HIPCHK(hipMalloc((void**)&c->xstatus, 2 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(c->xstatus, 0, 2 * sizeof(unsigned long long)));
+  HIPCHK(hipHostMalloc((void**)&c->xstatus_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  c->xstatus_host[0] = c->xstatus_host[1] = 0ull;
   HIPCHK(dalloc(&c->xflat, (size_t)up(c->L.n_params + 4, 64)));
   HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
 #ifdef IQL_STAMPS
@@ -399,6 +402,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
     if (c->sched_pin[i]) (void)hipHostFree(c->sched_pin[i]);
   }
   if (c->sched_ack) (void)hipHostFree(c->sched_ack);
+  if (c->xstatus_host) (void)hipHostFree(c->xstatus_host);
   if (c->setup_arrivals) (void)hipFree(c->setup_arrivals);
   if (c->losses_host) (void)hipHostFree(c->losses_host);
   if (c->on_row_pin) (void)hipHostFree(c->on_row_pin);
@@ -795,8 +799,22 @@ extern "C" int iqlhip_p2p_export(iqlhip_ctx* c, void* handle_out, int rank, int 
       c->xloss_off[k] = c->xslabb_off[k] + slabb_b;
     }
     c->xblk_bytes = flags_b + 2 * buf_b;
-    HIPCHK(hipMalloc((void**)&c->xblk, c->xblk_bytes));
+    // Coarse-grained device memory by default: the backward's plain stores into this block are complete AND written
+    // back to the device's memory at the kernel boundary in front of the flag kernel (dirty L2 lines leave at a
+    // boundary), and every peer reads them with system-scope loads that bypass its own caches — the data a peer can
+    // see is in this device's HBM before the flag that announces it is stored.  IQLHIP_P2P_FINEGRAINED=1 allocates the
+    // block fine-grained instead (no reliance on the boundary write-back; slower stores) where the runtime can export
+    // such memory through hipIpc; the replicas-equal check of the callers is the gate either way.
+    hipError_t ea = hipErrorUnknown;
+    if (getenv("IQLHIP_P2P_FINEGRAINED")) ea = hipExtMallocWithFlags((void**)&c->xblk, c->xblk_bytes, hipDeviceMallocFinegrained);
+    if (ea != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipMalloc((void**)&c->xblk, c->xblk_bytes)); }
     HIPCHK(hipMemset(c->xblk, 0, c->xblk_bytes));
+    HIPCHK(hipDeviceSynchronize());
+  } else {
+    // a second attach: every rank clears its OWN flag lines here, before the handles are exchanged (the callers'
+    // all-gather is the barrier), so no stale flag of an earlier group satisfies the first waits of the new one
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(c->xblk, 0, 4096));
     HIPCHK(hipDeviceSynchronize());
   }
   hipIpcMemHandle_t h;
@@ -863,6 +881,17 @@ extern "C" int iqlhip_xch_status(iqlhip_ctx* c, int64_t status[3], void* stream)
   return IQLHIP_OK;
 }
 
+// Forget a recorded wait timeout (after the caller has re-synchronised the replicas and chosen another exchange).
+extern "C" int iqlhip_xch_clear_status(iqlhip_ctx* c, void* stream) {
+  if (!c) return fail(IQLHIP_EINVAL, "NULL ctx");
+  DevGuard guard(c->device);
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemset(c->xstatus, 0, 2 * sizeof(unsigned long long)));
+  HIPCHK(hipDeviceSynchronize());
+  drop_graph(c);
+  return IQLHIP_OK;
+}
+
 extern "C" int iqlhip_xch_shutdown(iqlhip_ctx* c) {
   if (!c) return IQLHIP_OK;
   DevGuard guard(c->device);
@@ -877,6 +906,15 @@ extern "C" int iqlhip_xch_shutdown(iqlhip_ctx* c) {
   c->world = 1;
   c->rank = 0;
   return IQLHIP_OK;
+}
+
+// A P2P wait that timed out is sticky and silent on the device (later waits return at once and the update kernels sum
+// whatever the peers' buffers hold): the entry points that synchronise anyway read the status word along with the
+// losses and turn it into an error, so a run cannot keep training on unsynchronised gradients unnoticed.
+static int xch_poisoned(iqlhip_ctx* c, const unsigned long long* status_host) {
+  if (status_host[0] == 0ull) return IQLHIP_OK;
+  return fail(IQLHIP_EEXCHANGE, "the peer-to-peer gradient exchange timed out at exchange step %llu: a peer rank did not arrive; "
+              "the replicas are no longer synchronised", status_host[0]);
 }
 
 static XchParams make_xch(const iqlhip_ctx* c, bool from_hdr) {
@@ -1055,7 +1093,10 @@ extern "C" int iqlhip_online_step(iqlhip_ctx* c, float* rows_dev, int64_t ld, in
              : actor_forward_impl(c, c->on_act_pin, S, 1, nullptr, 0, 0, 0, max_action, a_out, A, stream);
     if (rc) return rc;
   }
+  const bool p2p_x = c->xch_mode == IQLHIP_XCH_P2P && c->world > 1;
+  if (p2p_x) HIPCHK(hipMemcpyAsync(c->xstatus_host, c->xstatus, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));        // (a synchronous call: the pinned staging words are free again on return)
+  if (p2p_x) { int rx = xch_poisoned(c, c->xstatus_host); if (rx) return rx; }
   out[0] = c->on_loss_pin[0]; out[1] = c->on_loss_pin[1]; out[2] = c->on_loss_pin[2];
   if (act_state_host) memcpy(act_out_host, c->on_act_pin + IQLHIP_MAX_INPUT, (size_t)A * sizeof(float));
   HIPCHK(hipGetLastError());
@@ -1097,21 +1138,25 @@ extern "C" int iqlhip_apply_update(iqlhip_ctx* c, const float* grads_dev, const 
 extern "C" int iqlhip_read_losses(iqlhip_ctx* c, float out[3], void* stream) {
   if (!c || !out) return fail(IQLHIP_EINVAL, "NULL argument");
   float* h = c->losses_host;
+  const bool p2p = c->xch_mode == IQLHIP_XCH_P2P && c->world > 1;
   HIPCHK(hipMemcpyAsync(h, c->sc.losses, 4 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (p2p) HIPCHK(hipMemcpyAsync(c->xstatus_host, c->xstatus, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
-  return IQLHIP_OK;
+  return p2p ? xch_poisoned(c, c->xstatus_host) : IQLHIP_OK;
 }
 
 extern "C" int iqlhip_read_loss_ring(iqlhip_ctx* c, float* out, int32_t n_steps, void* stream) {
   if (!c || !out) return fail(IQLHIP_EINVAL, "NULL argument");
   if (n_steps < 1 || n_steps > c->ring_cap) return fail(IQLHIP_EINVAL, "n_steps outside [1,%d]", c->ring_cap);
   std::vector<float> h((size_t)n_steps * 4);
+  const bool p2p = c->xch_mode == IQLHIP_XCH_P2P && c->world > 1;
   HIPCHK(hipMemcpyAsync(h.data(), c->loss_ring, h.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (p2p) HIPCHK(hipMemcpyAsync(c->xstatus_host, c->xstatus, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   for (int k = 0; k < n_steps; ++k)
     for (int j = 0; j < 3; ++j) out[3 * k + j] = h[4 * (size_t)k + j];
-  return IQLHIP_OK;
+  return p2p ? xch_poisoned(c, c->xstatus_host) : IQLHIP_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1549,6 +1594,21 @@ extern "C" int iqlhip_rows_normalize(float* rows_dev, int64_t ld, int32_t S, int
   const int nb = (int)std::min<long long>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(iql_rows_normalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows_dev, (long long)ld, S, A,
                      (long long)row0, (long long)n, mean_dev, std_dev);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int iqlhip_rows_fill_synth(float* rows_dev, int64_t ld, int32_t S, int32_t A, int64_t row0, int64_t n,
+                                      uint64_t seed, float p_done, int32_t antmaze_rewards, void* stream) {
+  if (!rows_dev) return fail(IQLHIP_EINVAL, "NULL argument");
+  if (n < 0 || row0 < 0 || S < 1 || A < 1 || ld < 2 * (int64_t)S + A + 2) return fail(IQLHIP_EINVAL, "bad rows_fill_synth geometry");
+  if (!(p_done >= 0.f && p_done <= 1.f)) return fail(IQLHIP_EINVAL, "p_done outside [0,1]");
+  if (n == 0) return IQLHIP_OK;
+  const long long total = (long long)n * (2 * S + A + 2);
+  const int nb = (int)std::min<long long>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(iql_rows_fill_synth_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows_dev, (long long)ld, S, A,
+                     (long long)row0, (long long)n, (unsigned long long)seed, p_done, (int)antmaze_rewards);
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }

@@ -979,6 +979,10 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   RT_ENTRY();
   const int bid = blockIdx.x;
   const int x = bid & 7;
+  // (destinations of the un-waited prefetch loads below: kept allocated until the asm that waits for them, behind the
+  //  pinned argument batch — hipcc does not track scalar loads inside inline asm and could otherwise hand the registers
+  //  to a live value before the loads have written them)
+  unsigned kpf[8];
   {
     // Touch every 64-byte line of the kernel-argument block this kernel reads, NOW and without waiting: hipcc fetches
     // the arguments in three to four dependent groups (the early-exit test first, then the pinned batch, then words it
@@ -998,6 +1002,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7)
         : "s"(ka), "s"(o_net), "s"(o_net + (unsigned)sizeof(NetPtrs) - 4u), "s"(o_go), "s"(o_go + (unsigned)sizeof(NetGrad) - 4u),
           "s"(o_t0), "s"(o_t0 + 64u), "s"(o_t0 + 128u), "s"(o_t0 + 192u));
+    kpf[0] = d0; kpf[1] = d1; kpf[2] = d2; kpf[3] = d3; kpf[4] = d4; kpf[5] = d5; kpf[6] = d6; kpf[7] = d7;
   }
   // A net's blocks stay on two XCDs (net = x & 3: its weights and activations live in those two L2s; rotating the nets
   // over all XCDs made multi-round launches 5-8 % SLOWER).  But the policy's blocks are 1.5-2.5x as long as the scalar
@@ -1050,6 +1055,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     PIN_S(p.inv_batch); PIN_S(p.hy.iql_tau); PIN_S(p.hy.beta); PIN_S(p.hy.discount); PIN_S(p.hy.exp_adv_max);
     PIN_S(n_chunk); PIN_S(n_rt);
   }
+  // the prefetch loads have landed by now (the pinned batch above was waited for with lgkmcnt(0), which covers every
+  // earlier scalar load): this wait is free, and its operands end the prefetch registers' live range HERE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(kpf[0]), "s"(kpf[1]), "s"(kpf[2]), "s"(kpf[3]), "s"(kpf[4]), "s"(kpf[5]), "s"(kpf[6]), "s"(kpf[7]));
   if (local_ >= n_a + n_b) return;
   // MULTI: the (b) blocks walk 2 / 4 slices and run 2-3x as long as a dW1 tile — they take the FIRST block indices so
   // that the launch ends on short blocks (longest first); one-slice grids keep the dW1 tiles first
@@ -2350,6 +2358,34 @@ __global__ void iql_draw_indices_kernel(long long* idx, long long n, long long s
     const unsigned long long r1 = ((unsigned long long)c[3] << 32) | c[2];
     idx[2 * i] = (long long)__umul64hi(r0, (unsigned long long)size);
     if (2 * i + 1 < n) idx[2 * i + 1] = (long long)__umul64hi(r1, (unsigned long long)size);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic D4RL-shaped rows generated where they will live (bench data, SURVEY §8d's distributions, not a parity
+// fixture): obs, next_obs ~ N(0,1); actions ~ U(-1,1) * 0.999; rewards ~ N(0,1) (antmaze flavour: -1 with p = 0.98,
+// else 0); dones ~ Bernoulli(p_done).  One Philox4x32-10 block per element (key = seed, counter = element number):
+// Box-Muller on two words for the normals.  At configs[3]'s 10 M rows the host generator of jsrl-corl_amd/synth.py takes
+// ~30 s per rank (and a 1.7 GB upload); this takes milliseconds and every rank produces identical rows.
+__global__ void iql_rows_fill_synth_kernel(float* rows, long long ld, int S, int A, long long row0, long long n,
+                                           unsigned long long seed, float p_done, int antmaze) {
+  const int W = 2 * S + A + 2;
+  const long long total = n * W;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / W;
+    const int c = (int)(e - i * W);
+    const unsigned long long ctr = (unsigned long long)(row0 + i) * (unsigned long long)W + (unsigned long long)c;
+    uint32_t k[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x46494C4Cu /* "FILL" */, 0u};
+    philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u1 = ((float)(k[0] >> 8) + 0.5f) * (1.f / 16777216.f);       // (0, 1)
+    const float u2 = ((float)(k[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+    float v;
+    if (c < S || (c >= S + A && c < 2 * S + A)) v = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    else if (c < S + A) v = (2.f * u1 - 1.f) * 0.999f;
+    else if (c == 2 * S + A) v = antmaze ? ((u1 < 0.98f) ? -1.f : 0.f) : sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    else v = (u1 < p_done) ? 1.f : 0.f;
+    rows[(row0 + i) * ld + c] = v;
   }
 }
 

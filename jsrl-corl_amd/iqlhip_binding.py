@@ -94,12 +94,15 @@ SYMBOLS = [
     ("iqlhip_p2p_attach", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("iqlhip_xch_select", C.c_int, [C.c_void_p, C.c_int]),
     ("iqlhip_xch_status", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    ("iqlhip_xch_clear_status", C.c_int, [C.c_void_p, C.c_void_p]),
     ("iqlhip_xch_shutdown", C.c_int, [C.c_void_p]),
     ("iqlhip_read_losses", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
     ("iqlhip_read_loss_ring", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_void_p]),
     ("iqlhip_row_stride", C.c_int64, [C.c_int32, C.c_int32]),
     ("iqlhip_rows_write", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("iqlhip_rows_fill_synth", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint64,
+                                         C.c_float, C.c_int32, C.c_void_p]),
     ("iqlhip_rows_gather", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("iqlhip_actor_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_float,

@@ -118,6 +118,24 @@ class ReplayBuffer:
         self._pointer = min(self._size, n_transitions)
         print(f"Dataset size: {n_transitions}")
 
+    def fill_synthetic(self, n_transitions: int, seed: int = 0, p_done: float = 0.01, antmaze_rewards: bool = False) -> None:
+        """Bench helper (not part of the reference's surface): fill the first n rows of an EMPTY buffer with synthetic
+        D4RL-shaped transitions generated on the device (SURVEY §8d's distributions) and account for them like
+        load_d4rl_dataset does (iql.py:153-169) — no host arrays, no upload; identical rows on every rank."""
+        if not self._gpu:
+            raise RuntimeError("iqlhip: fill_synthetic runs in libiqlhip.so and needs a GPU buffer")
+        if self._size != 0:
+            raise ValueError("Trying to load data into non-empty replay buffer")
+        if n_transitions > self._buffer_size:
+            raise ValueError("Replay buffer is smaller than the dataset you are trying to load!")
+        self._writes += 1
+        with torch.cuda.device(self._rows.device):
+            hb.check(hb.lib().iqlhip_rows_fill_synth(self._rows.data_ptr(), self._ld, self._state_dim, self._action_dim, 0,
+                                                     n_transitions, int(seed), float(p_done), int(antmaze_rewards),
+                                                     self._stream()))
+        self._size += n_transitions
+        self._pointer = min(self._size, n_transitions)
+
     # ---- dataset ingest on the device (SURVEY §8f N4; not part of the reference's surface) -------------------
     def state_mean_std(self, eps: float = 1e-3):
         """compute_mean_std (iql.py:77-80) of the stored `observations` column block, reduced on the device:

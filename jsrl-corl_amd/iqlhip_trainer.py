@@ -427,6 +427,10 @@ class ImplicitQLearning:
         buf = replay_buffer
         if not getattr(buf, "_gpu", False) or buf._rows.device != self._dev:
             raise ValueError("online_step needs a ReplayBuffer on the trainer's GPU")
+        if self._dp_world > 1 and self._dp_exchange == "torch":
+            raise NotImplementedError("online_step runs the whole step in one library call: it needs an in-library "
+                                      "exchange, enable_data_parallel(exchange='rccl'|'p2p') — with exchange='torch' "
+                                      "use add_transition / sample / train")
         S, A = self._S, self._A
         row = getattr(self, "_on_row", None)
         if row is None or row.shape[0] != buf._ld:
@@ -436,18 +440,18 @@ class ImplicitQLearning:
         row[S + A: 2 * S + A] = np.asarray(next_state, dtype=np.float32).reshape(-1)
         row[2 * S + A] = np.float32(reward)
         row[2 * S + A + 1] = np.float32(done)
+        # (the buffer's and the trainer's counters move only once the library call has succeeded)
         pointer = buf._pointer
-        buf._writes += 1
-        buf._pointer = (buf._pointer + 1) % buf._buffer_size
-        buf._size = min(buf._size + 1, buf._buffer_size)
-        idx = np.random.randint(0, buf._index_bound(), size=batch_size)
+        new_size = min(buf._size + 1, buf._buffer_size)
+        from iqlhip_replay import ReplayBuffer
+        if type(buf)._index_bound is not ReplayBuffer._index_bound or type(buf).add_transition is not ReplayBuffer.add_transition:
+            raise NotImplementedError("online_step needs the finetune ReplayBuffer (the offline flavour has no add_transition)")
+        idx = np.random.randint(0, new_size, size=batch_size)        # sample()'s draw over the size AFTER the insert
         if idx.dtype != np.int64:
             idx = idx.astype(np.int64)
-        self.total_it += 1
-        for g in self._adam_t:
-            self._adam_t[g] += 1
+        adam_next = {g: t + 1 for g, t in self._adam_t.items()}
         sc = hb.StepScalars()
-        self._fill_scalars(sc, self._adam_t, self._current_lrs(), dp.inv_batch(batch_size, self._dp_world))
+        self._fill_scalars(sc, adam_next, self._current_lrs(), dp.inv_batch(batch_size, self._dp_world))
         out = (C.c_float * 3)()
         a_in = a_out = None
         seed = 0
@@ -462,6 +466,11 @@ class ImplicitQLearning:
                                              row.ctypes.data, idx.ctypes.data, batch_size, C.byref(sc), out,
                                              None if a_in is None else a_in.ctypes.data, float(self.actor.max_action),
                                              seed, None if a_out is None else a_out.ctypes.data, self._stream()))
+        buf._writes += 1
+        buf._pointer = (pointer + 1) % buf._buffer_size
+        buf._size = new_size
+        self.total_it += 1
+        self._adam_t = adam_next
         self._advance_schedule(1)
         log = {"value_loss": float(out[0]), "q_loss": float(out[1]), "actor_loss": float(out[2])}
         return log if act_next is None else (log, a_out)
@@ -767,8 +776,37 @@ class ImplicitQLearning:
             # (train() / train_on_buffer(); train_steps needs an in-library exchange)
             self._dp_exchange = "torch"
 
+    def resync_replicas(self) -> None:
+        """Collective: make rank 0's state the common one again — the four arenas, the step counters and the actor's
+        schedule — and forget a recorded exchange timeout.  For a caller that found the replicas diverged (a probe of
+        an exchange that does not work on this machine) and is about to continue on another exchange."""
+        import torch.distributed as dist
+        self._require_gpu()
+        torch.cuda.synchronize(self._dev)
+        g = self._dp_group
+        src = dist.get_global_rank(g, 0) if g else 0
+        if dist.get_backend(g) == "gloo":
+            dp.broadcast_state_host((self._params_arena, self._target_arena, self._m_arena, self._v_arena), g, src)
+        else:
+            dp.broadcast_state((self._params_arena, self._target_arena, self._m_arena, self._v_arena), g, src)
+        box = [(self.total_it, dict(self._adam_t), self._schedule_state())] if self._dp_rank == 0 else [None]
+        dist.broadcast_object_list(box, src=src, group=g)
+        total_it, adam_t, (lr, e, count) = box[0]
+        self.total_it, self._adam_t = int(total_it), dict(adam_t)
+        if self.actor_lr_schedule is not None:
+            self._commit_schedule((lr, e, count))
+        else:
+            self.actor_optimizer.param_groups[0]["lr"] = lr
+        self._table_cache = None
+        self._ts_token = None
+        hb.check(hb.lib().iqlhip_xch_clear_status(self._ctx, self._stream()))
+
     def select_exchange(self, exchange: str) -> None:
         """Switch between attached in-library exchanges ("rccl" / "p2p"); collective: every rank must do the same."""
+        if exchange == "torch":           # the eager fallback: local steps in the library, torch.distributed in between
+            hb.check(hb.lib().iqlhip_xch_select(self._ctx, hb.XCH_NONE))
+            self._dp_exchange = "torch"
+            return
         mode = {"rccl": hb.XCH_RCCL, "p2p": hb.XCH_P2P}[exchange]
         hb.check(hb.lib().iqlhip_xch_select(self._ctx, mode))
         self._dp_exchange = exchange

@@ -129,8 +129,9 @@ class CpuIQL:
         return log
 
 
-def time_cpu_steps(S, A, B, n_rows, seconds_budget=15.0, threads=1, warmup=5, seed=0):
-    """steps/s of sample()+train() on `threads` host threads over a bounded sample."""
+def time_cpu_steps(S, A, B, n_rows, seconds_budget=15.0, threads=1, warmup=5, seed=0, max_steps=None):
+    """steps/s of sample()+train() on `threads` host threads over a bounded sample: `warmup` untimed steps (themselves
+    bounded by the budget), then steps until `max_steps` (>= 2 000 after 200 warm-up) or the budget."""
     import time
 
     import synth
@@ -139,13 +140,16 @@ def time_cpu_steps(S, A, B, n_rows, seconds_budget=15.0, threads=1, warmup=5, se
     buf = CpuReplay(data)
     tr = CpuIQL(S, A, params=synth.synth_params(S, A, seed=seed))
     np.random.seed(seed)
+    t_w = time.perf_counter()
     for _ in range(warmup):
         tr.train(buf.sample(B))
+        if time.perf_counter() - t_w > seconds_budget:      # (a slow host: the warm-up may not eat the whole run)
+            break
     n, t0 = 0, time.perf_counter()
     while True:
         tr.train(buf.sample(B))
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds_budget and n >= 5:       # (the budget is checked every step: a slow host cannot overrun it)
+        if (el >= seconds_budget and n >= 5) or (max_steps is not None and n >= max_steps):   # (checked every step)
             break
     return n / el, n, el

@@ -165,3 +165,36 @@ def test_p2p_absent_peer_times_out_instead_of_hanging(tmp_path):
     status word names the step — nothing hangs and the process exits cleanly."""
     res = _run_ranks("absent", 2, tmp_path, timeout=120)
     assert res[0]["status"]["timed_out_step"] == 1 and res[0]["status"]["steps"] == 3
+
+
+def _bench_two_ranks_one_gpu(extra_env, args=("--rows", "200000", "--steps", "40", "--warmup", "32"), timeout=420):
+    env = dict(os.environ)
+    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0", "IQLHIP_DIST_BACKEND": "gloo", "IQLHIP_PREPARE_WARM_CHUNKS": "0"})
+    env.update(extra_env)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline",
+           "--master-port", str(29300 + os.getpid() % 500)] + list(args)
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert out.returncode == 0, out.stderr.decode("utf-8", "replace")[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_recovers_from_an_exchange_probe_that_left_the_replicas_diverged():
+    """`bench.py --gpus 2 --exchange auto` when the peer-to-peer probe leaves the replicas REALLY diverged (test hook:
+    the last rank perturbs its parameters after the probe run) and RCCL is unavailable (two ranks on this one GPU): the
+    run must re-synchronise rank 0's arenas / step counters, clear the exchange status, fall back to the eager
+    torch.distributed exchange and finish with identical replicas (bench.py asserts that itself before it prints)."""
+    d = _bench_two_ranks_one_gpu({"IQLHIP_BENCH_BREAK_PROBE": "p2p"})
+    cfg = d["config"]
+    assert cfg["exchange"] == "torch" and "no in-library exchange" in cfg["exchange_why"]
+    assert cfg["exchange_probe"]["p2p"]["replicas_equal"] is False and cfg["exchange_probe"]["p2p"]["resynced"] is True
+    assert "unavailable" in cfg["exchange_probe"]["rccl"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "REHEARSAL" in cfg["multi_gpu_note"]
+
+
+def test_bench_two_ranks_on_one_gpu_pick_the_peer_exchange_and_say_why():
+    d = _bench_two_ranks_one_gpu({})
+    cfg = d["config"]
+    assert cfg["exchange"] == "p2p" and cfg["exchange_probe"]["p2p"]["replicas_equal"] is True
+    assert "only in-library exchange" in cfg["exchange_why"]

@@ -374,3 +374,26 @@ def test_return_reward_range_equals_the_sequential_definition():
         else:
             got = iql.return_reward_range(ds, limit)
             assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_bench_rank_supervisor_stops_everything_on_the_first_failure_and_on_timeout():
+    """bench.py's parent of self-launched ranks polls ALL children: one rank failing early must not leave the others
+    (and the parent) waiting in a collective until its timeout — they are terminated and the failure's code returned;
+    a run that exceeds the overall bound is terminated with 124."""
+    import subprocess
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sleeper = [sys.executable, "-c", "import time; time.sleep(60)"]
+    procs = [subprocess.Popen(sleeper), subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(3)"]),
+             subprocess.Popen(sleeper)]
+    t0 = time.monotonic()
+    assert bench.wait_ranks(procs, timeout_s=30.0) == 3
+    assert time.monotonic() - t0 < 10.0 and all(p.poll() is not None for p in procs)
+    procs = [subprocess.Popen(sleeper), subprocess.Popen(sleeper)]
+    t0 = time.monotonic()
+    assert bench.wait_ranks(procs, timeout_s=0.5) == 124
+    assert time.monotonic() - t0 < 10.0 and all(p.poll() is not None for p in procs)
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
+    assert bench.wait_ranks(ok, timeout_s=30.0) == 0
