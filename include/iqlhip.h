@@ -155,6 +155,16 @@ int iqlhip_bind(iqlhip_ctx* ctx, float* params_dev, float* target_dev, float* ex
  * three groups; Polyak.  Losses land in device words read by iqlhip_read_losses. */
 int iqlhip_step(iqlhip_ctx* ctx, const iqlhip_batch* batch, const iqlhip_step_scalars* sc, void* stream);
 
+/* The same step WITH the host synchronisation train() ends on (the three .item() calls of iql.py:491,509,535 as one):
+ * the losses land in host-mapped pinned words followed by a completion word the host spins on — no stream synchronise
+ * (12-17 us of host time after the GPU has finished, profiles/r03_sync_cost.txt).  Returns when out[3] = {value, q, actor}
+ * is there; the parameter update itself stays ordered by `stream` like after iqlhip_step. */
+int iqlhip_step_sync(iqlhip_ctx* ctx, const iqlhip_batch* batch, const iqlhip_step_scalars* sc, float out[3], void* stream);
+/* ... in two halves, for a host that has work to do while the GPU runs the step: begin launches, wait returns the
+ * losses of the step begun last. */
+int iqlhip_step_begin(iqlhip_ctx* ctx, const iqlhip_batch* batch, const iqlhip_step_scalars* sc, void* stream);
+int iqlhip_step_wait(iqlhip_ctx* ctx, float out[3], void* stream);
+
 /* One iteration of the online fine-tuning loop's device work (algorithms/finetune/iql.py:741-773, jsrl_w_iql.py:
  * 512-548: add_transition -> sample -> train) in one call: the new packed transition row_host[ld] is stored at ring
  * row `pointer` of rows_dev (capacity rows), the batch rows_dev[idx_host[0..n)] (indices as np.random.randint drew them,

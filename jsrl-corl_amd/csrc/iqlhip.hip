@@ -118,6 +118,8 @@ struct iqlhip_ctx {
   float* on_row_pin = nullptr;        // iqlhip_online_step: pinned, host-mapped staging of the new transition [row_ld]
   long long* on_idx_pin = nullptr;    // ... and of the sampled indices [max_batch]
   float* on_loss_pin = nullptr;       // ... and the landing words of the step's three losses [4]
+  unsigned long long* done_pin = nullptr;   // host-mapped completion word of the synchronous entry points (the host spins on it)
+  unsigned long long done_seq = 0;
   float* on_act_pin = nullptr;        // ... and of the follow-up act(): state in [IQLHIP_MAX_INPUT], action out [IQLHIP_MAX_ACTION]
   int act_cap = 0;
   unsigned long long act_calls = 0;   // Philox call counter of iqlhip_actor_sample
@@ -265,6 +267,8 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   HIPCHK(hipHostMalloc((void**)&c->on_row_pin, (size_t)c->row_ld * sizeof(float), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&c->on_idx_pin, (size_t)MB * sizeof(long long), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&c->on_loss_pin, 4 * sizeof(float), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&c->done_pin, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  memset(c->done_pin, 0, 8 * sizeof(unsigned long long));
   HIPCHK(hipHostMalloc((void**)&c->on_act_pin, (size_t)(IQLHIP_MAX_INPUT + IQLHIP_MAX_ACTION) * sizeof(float), hipHostMallocDefault));
   c->act_cap = std::max(MB, IQLHIP_ACT_ROWS);
   HIPCHK(dalloc(&c->xb_act, (size_t)c->act_cap * c->row_ld));
@@ -408,6 +412,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   if (c->on_row_pin) (void)hipHostFree(c->on_row_pin);
   if (c->on_idx_pin) (void)hipHostFree(c->on_idx_pin);
   if (c->on_loss_pin) (void)hipHostFree(c->on_loss_pin);
+  if (c->done_pin) (void)hipHostFree(c->done_pin);
   if (c->on_act_pin) (void)hipHostFree(c->on_act_pin);
   delete c;
   return IQLHIP_OK;
@@ -605,6 +610,7 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.sched_idx = 0;
   u.ring_hdr = nullptr;
   u.adv_hdr = nullptr; u.adv_k = 0; u.adv_rows = 0;
+  u.done_flag = nullptr; u.done_val = 0;
   u.n_peer = 0;
   u.peer_direct = 0;
   for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) { u.peer_flat[r] = nullptr; u.peer_slab_b[r] = nullptr; u.peer_loss[r] = nullptr; }
@@ -1015,7 +1021,61 @@ extern "C" int iqlhip_get_timing(iqlhip_ctx* c, float out_us[4]) {
   return IQLHIP_OK;
 }
 
+// Wait for the completion word of a synchronous entry point: spin on host-mapped memory (no HIP call: a stream
+// synchronise was measured at 12-17 us of host time AFTER the GPU had finished, profiles/r03_sync_cost.txt); bounded —
+// after 2 s the stream is synchronised the ordinary way, so a lost store cannot hang the caller.
+static int wait_done(iqlhip_ctx* c, unsigned long long val, hipStream_t st) {
+  const volatile unsigned long long* f = c->done_pin;
+  if (*f == val) return IQLHIP_OK;
+  const double t0 = now_us();
+  for (;;) {
+    for (int i = 0; i < 256; ++i) if (*f == val) return IQLHIP_OK;
+    if (now_us() - t0 > 2e6) break;
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  if (*f != val) return fail(IQLHIP_EHIP, "the step's completion word was not written");
+  return IQLHIP_OK;
+}
+
+static int step_impl(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_scalars* sc, float* out_sync, void* stream,
+                     bool defer_wait = false);
+
 extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_scalars* sc, void* stream) {
+  return step_impl(c, b, sc, nullptr, stream);
+}
+
+// ImplicitQLearning.train(batch) WITH its host synchronisation (the three .item() calls of iql.py:491,509,535 as one):
+// iqlhip_step + the losses, which land in host-mapped pinned words followed by a completion word the host spins on.
+// Returns once the losses are there; everything else the step does stays ordered by the stream as usual.
+extern "C" int iqlhip_step_sync(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_scalars* sc, float out[3], void* stream) {
+  if (!out) return fail(IQLHIP_EINVAL, "NULL argument");
+  return step_impl(c, b, sc, out, stream);
+}
+
+// The two halves of iqlhip_step_sync for a host that has something to do while the GPU runs the step (the Python shim
+// computes the NEXT step's float64 Adam / cosine scalars there): begin launches, wait returns the losses.
+extern "C" int iqlhip_step_begin(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_scalars* sc, void* stream) {
+  float dummy[3];
+  return step_impl(c, b, sc, dummy, stream, /*defer_wait=*/true);
+}
+extern "C" int iqlhip_step_wait(iqlhip_ctx* c, float out[3], void* stream) {
+  if (!c || !out) return fail(IQLHIP_EINVAL, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (c->xch_mode == IQLHIP_XCH_P2P && c->world > 1) {
+    HIPCHK(hipMemcpyAsync(c->xstatus_host, c->xstatus, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int rc = xch_poisoned(c, c->xstatus_host);
+    if (rc) return rc;
+  } else {
+    int rc = wait_done(c, c->done_seq, st);
+    if (rc) return rc;
+  }
+  out[0] = c->on_loss_pin[0]; out[1] = c->on_loss_pin[1]; out[2] = c->on_loss_pin[2];
+  return IQLHIP_OK;
+}
+
+static int step_impl(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_scalars* sc, float* out_sync, void* stream,
+                     bool defer_wait) {
   if (!c || !sc) return fail(IQLHIP_EINVAL, "NULL argument");
   int rc = check_batch(c, b);
   if (rc) return rc;
@@ -1029,6 +1089,13 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   StepParams p = make_step(c, b->rows, sc->inv_batch);
   p.xb = xb_cur;
   UpdParams u = make_upd(c, sc, b->rows, nullptr);
+  const bool p2p_x = c->xch_mode == IQLHIP_XCH_P2P && c->world > 1;
+  unsigned long long done_val = 0;
+  if (out_sync) {
+    u.losses_mirror = c->on_loss_pin;
+    u.done_flag = c->done_pin;
+    u.done_val = done_val = ++c->done_seq;
+  }
   hipEvent_t* ev = nullptr;
   if (c->timing) {
     if (c->ev_used + 4 > 4096) { rc = harvest_timing(c); if (rc) return rc; }
@@ -1042,12 +1109,25 @@ extern "C" int iqlhip_step(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_st
   if (rc) return rc;
   if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += 1;
   HIPCHK(hipGetLastError());
+  if (out_sync && !defer_wait) {
+    if (p2p_x) {       // (the exchange's status word has to come back too: the ordinary synchronise)
+      HIPCHK(hipMemcpyAsync(c->xstatus_host, c->xstatus, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      rc = xch_poisoned(c, c->xstatus_host);
+      if (rc) return rc;
+    } else {
+      rc = wait_done(c, done_val, st);
+      if (rc) return rc;
+    }
+    out_sync[0] = c->on_loss_pin[0]; out_sync[1] = c->on_loss_pin[1]; out_sync[2] = c->on_loss_pin[2];
+  }
   return IQLHIP_OK;
 }
 
 static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
                               int64_t ld_noise, uint64_t rng_seed, uint64_t rng_call, float max_action,
-                              float* actions_dev, int64_t ld_a, void* stream);
+                              float* actions_dev, int64_t ld_a, void* stream, unsigned long long* done_flag = nullptr,
+                              unsigned long long done_val = 0);
 
 // One iteration of the online loop's device work (algorithms/finetune/iql.py:741-773: add_transition -> sample ->
 // train) in ONE call and four launches: ring write + gather straight from pinned host words, forward, backward, update
@@ -1079,6 +1159,8 @@ extern "C" int iqlhip_online_step(iqlhip_ctx* c, float* rows_dev, int64_t ld, in
   StepParams p = make_step(c, n, sc->inv_batch);
   UpdParams u = make_upd(c, sc, n, nullptr);
   u.losses_mirror = c->on_loss_pin;
+  const unsigned long long done_val = ++c->done_seq;
+  if (!act_state_host) { u.done_flag = c->done_pin; u.done_val = done_val; }      // (else the follow-up act() signals)
   int rc = enqueue_step(c, p, u, c->xch_mode, (int)(c->xstep & 1ull), 0, /*from_hdr=*/false, st, nullptr);
   if (rc) return rc;
   if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += 1;
@@ -1089,14 +1171,24 @@ extern "C" int iqlhip_online_step(iqlhip_ctx* c, float* rows_dev, int64_t ld, in
     memcpy(c->on_act_pin, act_state_host, (size_t)S * sizeof(float));
     float* a_out = c->on_act_pin + IQLHIP_MAX_INPUT;
     rc = (act_seed != 0 && c->dims.policy == IQLHIP_POLICY_GAUSSIAN)
-             ? actor_forward_impl(c, c->on_act_pin, S, 1, nullptr, 0, act_seed, c->act_calls++, max_action, a_out, A, stream)
-             : actor_forward_impl(c, c->on_act_pin, S, 1, nullptr, 0, 0, 0, max_action, a_out, A, stream);
+             ? actor_forward_impl(c, c->on_act_pin, S, 1, nullptr, 0, act_seed, c->act_calls++, max_action, a_out, A, stream, c->done_pin, done_val)
+             : actor_forward_impl(c, c->on_act_pin, S, 1, nullptr, 0, 0, 0, max_action, a_out, A, stream, c->done_pin, done_val);
     if (rc) return rc;
   }
+  // (a synchronous call: the pinned staging words are free again on return)
   const bool p2p_x = c->xch_mode == IQLHIP_XCH_P2P && c->world > 1;
-  if (p2p_x) HIPCHK(hipMemcpyAsync(c->xstatus_host, c->xstatus, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));        // (a synchronous call: the pinned staging words are free again on return)
-  if (p2p_x) { int rx = xch_poisoned(c, c->xstatus_host); if (rx) return rx; }
+  if (p2p_x) {
+    HIPCHK(hipMemcpyAsync(c->xstatus_host, c->xstatus, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int rx = xch_poisoned(c, c->xstatus_host);
+    if (rx) return rx;
+  } else {
+    // the completion word comes from the last kernel of the call; the whole call's kernels precede it in the stream
+    // EXCEPT that the update's flag is stored by its first block — the ring write and the gather (first launch) are
+    // long done by then, and the pinned words read below were written before the flag (release)
+    rc = wait_done(c, done_val, st);
+    if (rc) return rc;
+  }
   out[0] = c->on_loss_pin[0]; out[1] = c->on_loss_pin[1]; out[2] = c->on_loss_pin[2];
   if (act_state_host) memcpy(act_out_host, c->on_act_pin + IQLHIP_MAX_INPUT, (size_t)A * sizeof(float));
   HIPCHK(hipGetLastError());
@@ -1683,46 +1775,71 @@ namespace {
 struct SampleStage {
   int device = -1;
   int64_t cap = 0;
-  int64_t* host[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
-  int64_t* dev = nullptr;
+  enum { SLOTS = 8 };
+  int64_t* host[SLOTS] = {};             // pinned, host-mapped index slots the gather kernel reads in place
+  unsigned long long want[SLOTS] = {};   // the call number whose kernel must have acknowledged the slot before reuse
+  hipStream_t stream[SLOTS] = {};
+  unsigned long long* ack = nullptr;     // pinned [SLOTS]: written by the gather kernels
+  unsigned* arrivals = nullptr;          // device block counter
+  unsigned long long seq = 0;
   int slot = 0;
 };
 SampleStage g_stage[16];
 }  // namespace
 
+// ReplayBuffer.sample in one call from ORDINARY host memory (the array np.random.randint returned): the indices are
+// copied into a pinned, host-mapped slot owned by the library and the gather kernel reads them THERE (2 KB over PCIe) —
+// no H2D copy, no event; a slot is reused only after its kernel has acknowledged it in a host-mapped word.  Per-device
+// state, created on first use; like the rest of the ABI not thread-safe.
 extern "C" int iqlhip_rows_sample_packed(const float* rows_dev, int64_t ld, int64_t n_rows, const int64_t* idx_host,
                                          int64_t n, float* out_rows_dev, void* stream) {
   if (!rows_dev || !idx_host || !out_rows_dev) return fail(IQLHIP_EINVAL, "NULL argument");
-  if (n < 0 || n_rows < 1) return fail(IQLHIP_EINVAL, "bad rows_sample_packed geometry");
+  if (n < 0 || n_rows < 1 || ld < 4 || (ld & 3)) return fail(IQLHIP_EINVAL, "bad rows_sample_packed geometry");
+  if ((((uintptr_t)rows_dev) | ((uintptr_t)out_rows_dev)) & 15) return fail(IQLHIP_EINVAL, "rows must be 16-byte aligned");
   if (n == 0) return IQLHIP_OK;
   {
     int rc = check_host_indices(idx_host, n, n_rows);
     if (rc) return rc;
   }
+  const long long total = (long long)n * (ld / 4);
+  if (total > 0x7fffffffLL) return fail(IQLHIP_EINVAL, "gather too large for one call");
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return fail(IQLHIP_EUNSUPPORTED, "device index %d", dev);
   SampleStage& sg = g_stage[dev];
   if (sg.cap < n) {
     HIPCHK(hipDeviceSynchronize());          // nothing may still read the old staging
-    for (int i = 0; i < 4; ++i) {
-      if (sg.host[i]) (void)hipHostFree(sg.host[i]);
-      if (!sg.done[i]) HIPCHK(hipEventCreateWithFlags(&sg.done[i], hipEventDisableTiming));
-    }
-    if (sg.dev) (void)hipFree(sg.dev);
+    for (int i = 0; i < SampleStage::SLOTS; ++i) if (sg.host[i]) { (void)hipHostFree(sg.host[i]); sg.host[i] = nullptr; }
     sg.cap = std::max<int64_t>(n, 1024);
-    for (int i = 0; i < 4; ++i) HIPCHK(hipHostMalloc((void**)&sg.host[i], (size_t)sg.cap * sizeof(int64_t), hipHostMallocDefault));
-    HIPCHK(hipMalloc((void**)&sg.dev, (size_t)sg.cap * sizeof(int64_t)));
+    for (int i = 0; i < SampleStage::SLOTS; ++i) {
+      HIPCHK(hipHostMalloc((void**)&sg.host[i], (size_t)sg.cap * sizeof(int64_t), hipHostMallocDefault));
+      sg.want[i] = 0;
+    }
+    if (!sg.ack) {
+      HIPCHK(hipHostMalloc((void**)&sg.ack, SampleStage::SLOTS * sizeof(unsigned long long), hipHostMallocDefault));
+      memset(sg.ack, 0, SampleStage::SLOTS * sizeof(unsigned long long));
+      HIPCHK(hipMalloc((void**)&sg.arrivals, 64));
+      HIPCHK(hipMemset(sg.arrivals, 0, 64));
+      HIPCHK(hipDeviceSynchronize());
+    }
     sg.device = dev;
   }
   const int k = sg.slot;
-  sg.slot = (sg.slot + 1) & 3;
-  HIPCHK(hipEventSynchronize(sg.done[k]));   // returns at once unless this slot's previous copy has not run yet
+  sg.slot = (sg.slot + 1) % SampleStage::SLOTS;
+  {
+    const volatile unsigned long long* ack = sg.ack + k;
+    if (*ack < sg.want[k]) {                 // eight samples deep in flight: wait for that slot's kernel
+      for (int spin = 0; spin < 20000 && *ack < sg.want[k]; ++spin) {}
+      if (*ack < sg.want[k] && sg.stream[k]) HIPCHK(hipStreamSynchronize(sg.stream[k]));
+    }
+  }
   memcpy(sg.host[k], idx_host, (size_t)n * sizeof(int64_t));
-  HIPCHK(hipMemcpyAsync(sg.dev, sg.host[k], (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream));
-  HIPCHK(hipEventRecord(sg.done[k], (hipStream_t)stream));
-  return iqlhip_rows_gather_packed(rows_dev, ld, n_rows, sg.dev, n, out_rows_dev, stream);
+  sg.want[k] = ++sg.seq;
+  sg.stream[k] = (hipStream_t)stream;
+  hipLaunchKernelGGL(iql_gather_hostidx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows_dev,
+                     (long long)ld, (const long long*)sg.host[k], out_rows_dev, (int)n, sg.arrivals, sg.ack + k, sg.want[k]);
+  HIPCHK(hipGetLastError());
+  return IQLHIP_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1745,7 +1862,8 @@ extern "C" int iqlhip_actor_sample(iqlhip_ctx* c, const float* states_dev, int64
 
 static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld_s, int32_t rows, const float* noise_dev,
                               int64_t ld_noise, uint64_t rng_seed, uint64_t rng_call, float max_action,
-                              float* actions_dev, int64_t ld_a, void* stream) {
+                              float* actions_dev, int64_t ld_a, void* stream, unsigned long long* done_flag,
+                              unsigned long long done_val) {
   if (!c || !states_dev || !actions_dev) return fail(IQLHIP_EINVAL, "NULL argument");
   if (!c->params) return fail(IQLHIP_EINVAL, "iqlhip_bind has not been called");
   const int S = c->dims.state_dim, A = c->dims.action_dim;
@@ -1767,7 +1885,9 @@ static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld
   launch_fwd_grid(c, p, n_rt * NSPLIT, st);
   hipLaunchKernelGGL(iql_actor_finish_kernel, dim3((rows * A + 255) / 256), dim3(256), 0, st, c->heads_act, rows, A,
                      max_action, p.log_std, c->hyper.log_std_min, c->hyper.log_std_max, noise_dev, (long long)ld_noise,
-                     (unsigned long long)rng_seed, (unsigned long long)rng_call, actions_dev, (long long)ld_a);
+                     (unsigned long long)rng_seed, (unsigned long long)rng_call, actions_dev, (long long)ld_a,
+                     (rows * A <= 256) ? done_flag : (unsigned long long*)nullptr, done_val);
+  if (done_flag && rows * A > 256) return fail(IQLHIP_EINVAL, "a completion flag needs a one-block finish launch");
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }

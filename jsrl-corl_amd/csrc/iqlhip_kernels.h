@@ -1887,6 +1887,12 @@ struct UpdParams {
   // kernel), so the next chunk of the call starts without a host-side launch in between; null elsewhere
   unsigned long long* adv_hdr;
   int adv_k, adv_rows;
+  // eager steps that return the losses to the host: after the three loss words have been written to losses_mirror
+  // (host-mapped pinned memory) this host-mapped word receives done_val (release, system scope) — the host spins on it
+  // instead of calling a HIP synchronise (measured 12-17 us of host time after the GPU has finished).  Everything else
+  // a caller can observe of the step is ordered by the stream as before.  Null elsewhere.
+  unsigned long long* done_flag;
+  unsigned long long done_val;
 };
 
 __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
@@ -2006,6 +2012,32 @@ __global__ void iql_debug_flag_kernel(unsigned long long* flag, unsigned long lo
 __global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long long ld, const long long* idx,
                                                          float* xb, int n, long long n_rows) {
   gather_rows_flat(rows, ld, idx, xb, n, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, n_rows);
+}
+// The same with the indices read straight from a pinned, host-mapped slot (ReplayBuffer.sample: no H2D copy, no
+// event): every block first parks the indices of ITS rows in LDS, then the block that finishes last acknowledges the
+// slot in a host-mapped word — the host reuses the slot once it sees the call's number there (cf. iql_call_setup_kernel).
+__global__ __launch_bounds__(256) void iql_gather_hostidx_kernel(const float* rows, long long ld, const long long* idx_host,
+                                                                 float* xb, int n, unsigned* arrivals,
+                                                                 unsigned long long* ack, unsigned long long ack_val) {
+  __shared__ long long s_idx[260];
+  const int q = (int)(ld >> 2);
+  const int e0 = (int)blockIdx.x * 256;
+  const int r_first = e0 / q;
+  const int r_last = min((e0 + 255) / q, n - 1);
+  if ((int)threadIdx.x <= r_last - r_first) s_idx[threadIdx.x] = idx_host[r_first + threadIdx.x];
+  __syncthreads();                       // (the slot's words this block needs have been read)
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == gridDim.x) {
+      __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ack, ack_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  const int e = e0 + (int)threadIdx.x;
+  if (e < n * q) {
+    const int r = e / q, c4 = e - r * q;
+    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = *(const f32x4*)(rows + s_idx[r - r_first] * ld + 4 * c4);
+  }
 }
 
 // 16-byte accesses at SYSTEM scope (sc0 sc1): the load misses every cache level that is not coherent with another
@@ -2228,6 +2260,7 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     }
     u.losses[0] = l[0]; u.losses[1] = l[1]; u.losses[2] = l[2];
     if (u.losses_mirror) { u.losses_mirror[0] = l[0]; u.losses_mirror[1] = l[1]; u.losses_mirror[2] = l[2]; }
+    if (u.done_flag) __hip_atomic_store(u.done_flag, u.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (u.loss_ring) {
       const long long slot = (long long)u.ring_slot + (u.ring_hdr ? (long long)u.ring_hdr[HDR_BASE] : 0ll);
       float* rr = u.loss_ring + 4 * slot;
@@ -2258,12 +2291,10 @@ __global__ void iql_pack_states_kernel(float* xb, int ld, int S, int n, const fl
 // noise: caller-supplied N(0,1) values, or — rng_seed != 0 — drawn here: Philox4x32-10 keyed by the seed, counter
 // (element, call), Box-Muller on two of its words (the draw of dist.sample(), iql.py:376, without a host-side
 // random-number launch per env step).
-__global__ void iql_actor_finish_kernel(const float* heads_pi, int n, int A, float max_action, const float* log_std,
-                                        float ls_min, float ls_max, const float* noise, long long ld_noise,
-                                        unsigned long long rng_seed, unsigned long long rng_call, float* out,
-                                        long long ld_out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n * A) return;
+__device__ __forceinline__ void actor_finish_elem(const float* heads_pi, int e, int A, float max_action, const float* log_std,
+                                                  float ls_min, float ls_max, const float* noise, long long ld_noise,
+                                                  unsigned long long rng_seed, unsigned long long rng_call, float* out,
+                                                  long long ld_out) {
   const int row = e / A, dd = e - row * A;
   const f32x4 hp = *(const f32x4*)(heads_pi + (long long)e * NSPLIT);
   float a = tanh_via_exp(((hp[0] + hp[1]) + hp[2]) + hp[3]);      // same fixed order as the training step (sum4)
@@ -2282,6 +2313,21 @@ __global__ void iql_actor_finish_kernel(const float* heads_pi, int n, int A, flo
     a = a + sigma * z;
   }
   out[row * ld_out + dd] = fminf(fmaxf(a * max_action, -max_action), max_action);
+}
+// done_flag (nullable; one-block launches only): after every thread's store — ordered by the system-scope fence and
+// the barrier — a host-mapped word receives done_val: the host of iqlhip_online_step spins on it instead of
+// synchronising the stream.
+__global__ void iql_actor_finish_kernel(const float* heads_pi, int n, int A, float max_action, const float* log_std,
+                                        float ls_min, float ls_max, const float* noise, long long ld_noise,
+                                        unsigned long long rng_seed, unsigned long long rng_call, float* out,
+                                        long long ld_out, unsigned long long* done_flag, unsigned long long done_val) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n * A) actor_finish_elem(heads_pi, e, A, max_action, log_std, ls_min, ls_max, noise, ld_noise, rng_seed, rng_call, out, ld_out);
+  if (done_flag) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // Five row-major arrays (any strides) -> packed rows [s | a | s' | r | d | pad] of the staging batch.

@@ -79,6 +79,9 @@ SYMBOLS = [
     ("iqlhip_set_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("iqlhip_debug_write_masks", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("iqlhip_step", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(StepScalars), C.c_void_p]),
+    ("iqlhip_step_sync", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(StepScalars), C.POINTER(C.c_float), C.c_void_p]),
+    ("iqlhip_step_begin", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(StepScalars), C.c_void_p]),
+    ("iqlhip_step_wait", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
     ("iqlhip_online_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.POINTER(StepScalars), C.POINTER(C.c_float), C.c_void_p, C.c_float,
                                      C.c_uint64, C.c_void_p, C.c_void_p]),

@@ -21,6 +21,9 @@ import iqlhip_binding as hb
 
 TensorBatch = List[torch.Tensor]
 
+# (data_ptr of the observations view, rows, S, A, row stride, device) of the block the last GPU sample() produced
+_last_block = None
+
 
 def _is_gpu(device) -> bool:
     return torch.device(device).type == "cuda"
@@ -45,6 +48,9 @@ class ReplayBuffer:
         w = 2 * state_dim + action_dim + 2
         self._ld = hb.row_stride(state_dim, action_dim) if self._gpu else (w + 3) // 4 * 4
         self._rows = torch.zeros((buffer_size, self._ld), dtype=torch.float32, device=device)
+        self._rows_ptr = self._rows.data_ptr()
+        pad = self._ld - w
+        self._split_sizes = [state_dim, action_dim, state_dim, 1, 1] + ([pad] if pad else [])
         # bumped by every method that writes rows: ImplicitQLearning.train_steps may start a call on rows its previous
         # call staged ahead only while the buffer's contents are what they were then
         self._writes = 0
@@ -252,19 +258,23 @@ class ReplayBuffer:
         indices = np.random.randint(0, self._index_bound(), size=batch_size)
         if indices.dtype != np.int64:
             indices = indices.astype(np.int64)
-        S, A = self._state_dim, self._action_dim
         dev = self._rows.device
         block = torch.empty((batch_size, self._ld), dtype=torch.float32, device=dev)
         if torch.cuda.current_device() == dev.index:
-            hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows.data_ptr(), self._ld, self._buffer_size,
+            hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows_ptr, self._ld, self._buffer_size,
                                                         indices.ctypes.data, batch_size, block.data_ptr(), self._stream()))
         else:
             with torch.cuda.device(dev):
-                hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows.data_ptr(), self._ld, self._buffer_size,
+                hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows_ptr, self._ld, self._buffer_size,
                                                             indices.ctypes.data, batch_size, block.data_ptr(),
                                                             self._stream()))
-        return [block[:, :S], block[:, S: S + A], block[:, 2 * S + A: 2 * S + A + 1], block[:, S + A: 2 * S + A],
-                block[:, 2 * S + A + 1: 2 * S + A + 2]]
+        # five views of the block in ONE split (s, a, s', r, d[, pad]) -> the reference's order s, a, r, s', d
+        parts = block.split(self._split_sizes, dim=1)
+        batch = [parts[0], parts[1], parts[3], parts[2], parts[4]]
+        # ImplicitQLearning.train recognises a batch that IS such a freshly gathered block (it is consumed in place)
+        global _last_block
+        _last_block = (batch[0].data_ptr(), batch_size, self._state_dim, self._action_dim, self._ld, dev)
+        return batch
 
     def add_transition(self, state: np.ndarray, action: np.ndarray, reward: float, next_state: np.ndarray,
                        done: bool):

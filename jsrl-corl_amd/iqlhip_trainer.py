@@ -87,6 +87,8 @@ class ImplicitQLearning:
         self._dp_exchange = None      # None | "rccl" | "p2p" (in-library) | "torch" (torch.distributed.all_reduce)
         self._table_cache = None
         self._ts_token = None         # (buffer, its write count) of the last train_steps call
+        self._eager_next = None       # scalars of the next eager step, computed ahead (train() on a fresh sample() block)
+        self._loss_out = (C.c_float * 3)()
 
         self._ctx = None
         self._max_batch = 0
@@ -407,10 +409,73 @@ class ImplicitQLearning:
         """One IQL gradient step (iql.py:542-563).  Returns the three losses as floats
         (one host sync instead of the reference's three .item() calls)."""
         self._require_gpu()
+        fast = self._fresh_block_batch(batch)
+        if fast is not None:
+            return self._train_fresh_block(*fast)
         b, keep, B = self._batch_struct(batch)
         self._prepare(B)
         log = self._run_step(b, B, sync=True)
         del keep
+        return log
+
+    # ---- the reference loop's `batch = buffer.sample(B); trainer.train(batch)` (finetune/iql.py:771-773): the batch IS
+    # the block ReplayBuffer.sample just gathered — no per-tensor inspection, scalars computed while the GPU ran the
+    # previous step, losses through host-mapped words the library spins on (iqlhip_step_sync)
+    def _fresh_block_batch(self, batch):
+        import iqlhip_replay as rp
+        lb = rp._last_block
+        if lb is None or self._dp_world > 1 or len(batch) != 5:
+            return None
+        ptr, B, S, A, ld, dev = lb
+        o = batch[0]
+        if o.data_ptr() != ptr or S != self._S or A != self._A or dev != self._dev or o.shape[0] != B:
+            return None
+        # the other four must be that block's views too (a caller may have swapped one for its own tensor)
+        if (batch[1].data_ptr() != ptr + 4 * S or batch[3].data_ptr() != ptr + 4 * (S + A)
+                or batch[2].data_ptr() != ptr + 4 * (2 * S + A) or batch[4].data_ptr() != ptr + 4 * (2 * S + A + 1)):
+            return None
+        return ptr, B, ld
+
+    def _train_fresh_block(self, ptr: int, B: int, ld: int) -> Dict[str, float]:
+        self._prepare(B)
+        S, A = self._S, self._A
+        b = hb.Batch(ptr, ptr + 4 * S, ptr + 4 * (2 * S + A), ptr + 4 * (S + A), ptr + 4 * (2 * S + A + 1),
+                     ld, ld, ld, ld, ld, None, B)
+        inv_batch = 1.0 / B
+        pre = self._eager_next
+        self._eager_next = None
+        key = self._table_key(inv_batch)
+        if pre is not None and pre[0] == key:
+            sc, lr_after, sched_after = pre[1], pre[2], pre[3]
+        else:
+            t1 = {g: t + 1 for g, t in self._adam_t.items()}
+            sc = hb.StepScalars()
+            self._fill_scalars(sc, t1, self._current_lrs(), inv_batch)
+            pk = self._peek_schedule(1)
+            lr_after, sched_after = (None, None) if pk is None else (None, pk[1])
+        lib, stream, out = hb.lib(), self._stream(), self._loss_out
+        rc = lib.iqlhip_step_begin(self._ctx, C.byref(b), C.byref(sc), stream)
+        if rc:
+            hb.check(rc)
+        # ---- the GPU runs the step: host bookkeeping and the NEXT step's scalars (float64 Adam bias corrections, the
+        # cosine learning rate) now; a set computed ahead is used only if nothing it depends on has changed by then
+        self.total_it += 1
+        for g in self._adam_t:
+            self._adam_t[g] += 1
+        if sched_after is not None:
+            self._commit_schedule(sched_after)
+        else:
+            self._advance_schedule(1)
+        pk = self._peek_schedule(1)
+        if pk is not None:
+            t2 = {g: t + 1 for g, t in self._adam_t.items()}
+            sc2 = hb.StepScalars()
+            self._fill_scalars(sc2, t2, self._current_lrs(), inv_batch)
+            self._eager_next = (self._table_key(inv_batch), sc2, None, pk[1])
+        rc = lib.iqlhip_step_wait(self._ctx, out, stream)
+        if rc:
+            hb.check(rc)
+        log = {"value_loss": float(out[0]), "q_loss": float(out[1]), "actor_loss": float(out[2])}
         return log
 
     def online_step(self, replay_buffer, state, action, reward: float, next_state, done: bool,
