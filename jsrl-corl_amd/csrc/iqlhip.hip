@@ -131,6 +131,9 @@ struct iqlhip_ctx {
   unsigned long long drop_seed = 0, drop_step = 0;
   bool drop_inject = false;           // tests: masks were written by iqlhip_debug_write_masks, do not regenerate
   int precision = 0;                  // 0: fp32 MFMA everywhere; 1: bf16 operands for the layer-0/1, dW1, dH0, dW0 products
+  __bf16* wsh = nullptr;              // bf16 path: shadow of the parameter arena [n_params] (W1 is read from it) ...
+  __bf16* tsh = nullptr;              // ... and of the target arena [n_target]; written by the update kernel, refreshed
+                                      // from the fp32 masters at the start of every library call
   float* loss_ring = nullptr;         // [ring_cap][4]
   int ring_cap = 0;
   iqlhip_step_scalars* sched_cur = nullptr;   // [GRAPH_STEPS] device: per-step scalars of the chunk in flight
@@ -400,7 +403,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
                   c->flat_tmp, c->loss_ring, c->sched_call, c->sched_cur, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act,
-                  c->heads_act, c->drop_bits, c->xstatus, c->xflat};
+                  c->heads_act, c->drop_bits, c->xstatus, c->xflat, c->wsh, c->tsh};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < 4; ++i) {
     if (c->sched_pin[i]) (void)hipHostFree(c->sched_pin[i]);
@@ -429,6 +432,11 @@ extern "C" int iqlhip_set_precision(iqlhip_ctx* c, int mode) {
   if (!c) return fail(IQLHIP_EINVAL, "NULL ctx");
   if (mode != 0 && mode != 1) return fail(IQLHIP_EINVAL, "precision mode must be 0 (f32) or 1 (bf16 operands)");
   if (mode != c->precision) drop_graph(c);
+  if (mode == 1 && !c->wsh) {
+    DevGuard guard(c->device);
+    HIPCHK(hipMalloc((void**)&c->wsh, (size_t)up(c->L.n_params, 64) * sizeof(__bf16)));
+    HIPCHK(hipMalloc((void**)&c->tsh, (size_t)up(c->L.n_target, 64) * sizeof(__bf16)));
+  }
   c->precision = mode;
   return IQLHIP_OK;
 }
@@ -564,8 +572,17 @@ static StepParams make_step(const iqlhip_ctx* c, int rows, float inv_batch) {
   p.inst[5] = net_ptrs(L.net[IQLHIP_NET_Q2], c->params); p.xoff[5] = 0;     p.slot[5] = 2;
   p.inst[6] = net_ptrs(L.net[IQLHIP_NET_PI], c->params); p.xoff[6] = 0;     p.slot[6] = 3;
   p.inst[7] = p.inst[6]; p.xoff[7] = 0; p.slot[7] = -1;
+  if (c->precision == 1) {
+    // bf16 path: the kernels read W1 from the bf16 shadows (same element offsets); the field carries that address
+    const __bf16* wb = c->wsh;
+    const __bf16* tbs = c->tsh - L.target_src;
+    const int netof[7] = {IQLHIP_NET_V, IQLHIP_NET_V, IQLHIP_NET_Q1, IQLHIP_NET_Q2, IQLHIP_NET_Q1, IQLHIP_NET_Q2, IQLHIP_NET_PI};
+    for (int i = 0; i < 7; ++i) p.inst[i].w1 = (const float*)(((i == 2 || i == 3) ? tbs : wb) + L.net[netof[i]].w1);
+    p.inst[7].w1 = p.inst[6].w1;
+  }
   for (int n = 0; n < 4; ++n) {
     p.net[n] = net_ptrs(L.net[n], c->params);
+    if (c->precision == 1) p.net[n].w1 = (const float*)(c->wsh + L.net[n].w1);
     p.go[n].w1 = L.net[n].w1; p.go[n].b1 = L.net[n].b1; p.go[n].w2 = L.net[n].w2; p.go[n].b2 = L.net[n].b2;
     p.go[n].log_std = L.net[n].log_std;
   }
@@ -611,6 +628,8 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.ring_hdr = nullptr;
   u.adv_hdr = nullptr; u.adv_k = 0; u.adv_rows = 0;
   u.done_flag = nullptr; u.done_val = 0;
+  u.wsh = (c->precision == 1) ? c->wsh : nullptr;
+  u.tsh = (c->precision == 1) ? c->tsh : nullptr;
   u.n_peer = 0;
   u.peer_direct = 0;
   for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) { u.peer_flat[r] = nullptr; u.peer_slab_b[r] = nullptr; u.peer_loss[r] = nullptr; }
@@ -713,6 +732,15 @@ static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
   if (u.sched) { if (peer) UPD_LAUNCH(true, true); else UPD_LAUNCH(true, false); }
   else         { if (peer) UPD_LAUNCH(false, true); else UPD_LAUNCH(false, false); }
 #undef UPD_LAUNCH
+}
+
+// bf16 path: rebuild the bf16 shadows from the fp32 masters (the caller owns the masters and may have written them
+// through its own tensors — load_state_dict, a broadcast — since the last update kernel kept the shadows current).
+static void refresh_shadows(const iqlhip_ctx* c, hipStream_t st) {
+  if (c->precision != 1) return;
+  const long long n = std::max<long long>(c->L.n_params, c->L.n_target);
+  hipLaunchKernelGGL(iql_shadow_refresh_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, c->params, c->target,
+                     c->wsh, c->tsh, (long long)c->L.n_params, (long long)c->L.n_target);
 }
 
 static void launch_flatten(const iqlhip_ctx* c, const UpdParams& u, float* out, bool sys, hipStream_t st) {
@@ -1085,6 +1113,7 @@ static int step_impl(iqlhip_ctx* c, const iqlhip_batch* b, const iqlhip_step_sca
   const float* xb_cur = nullptr;
   rc = stage_batch(c, b, st, &xb_cur);
   if (rc) return rc;
+  refresh_shadows(c, st);
   if (c->drop_p > 0.f && !c->drop_inject) launch_dropmask(c, c->drop_seed, c->drop_step++, nullptr, 0, st);
   StepParams p = make_step(c, b->rows, sc->inv_batch);
   p.xb = xb_cur;
@@ -1155,6 +1184,7 @@ extern "C" int iqlhip_online_step(iqlhip_ctx* c, float* rows_dev, int64_t ld, in
   const int total = n * (int)(ld / 4);
   hipLaunchKernelGGL(iql_online_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, st, rows_dev, (long long)ld,
                      (long long)pointer, (const float*)c->on_row_pin, (const long long*)c->on_idx_pin, c->xb, n);
+  refresh_shadows(c, st);
   if (c->drop_p > 0.f && !c->drop_inject) launch_dropmask(c, c->drop_seed, c->drop_step++, nullptr, 0, st);
   StepParams p = make_step(c, n, sc->inv_batch);
   UpdParams u = make_upd(c, sc, n, nullptr);
@@ -1206,6 +1236,7 @@ extern "C" int iqlhip_forward_backward(iqlhip_ctx* c, const iqlhip_batch* b, con
   const float* xb_cur = nullptr;
   rc = stage_batch(c, b, st, &xb_cur);
   if (rc) return rc;
+  refresh_shadows(c, st);
   if (c->drop_p > 0.f && !c->drop_inject) launch_dropmask(c, c->drop_seed, c->drop_step++, nullptr, 0, st);
   StepParams p = make_step(c, b->rows, sc->inv_batch);
   p.xb = xb_cur;
@@ -1503,6 +1534,7 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
   };
   hipError_t e = copy_all(false);
   if (e != hipSuccess) { (void)hipFree(save); return fail(IQLHIP_EHIP, "prepare: save arenas: %s", hipGetErrorString(e)); }
+  refresh_shadows(c, cs);
   int slot = 0;
   rc = acquire_sched_slot(c, &slot);
   if (rc) { (void)hipFree(save); return rc; }
@@ -1557,6 +1589,7 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
   } while (0);
   c->drop_step = drop_step0;            // (the rehearsal drew keep-bits from the stream's current position; it is not advanced)
   e = copy_all(true);
+  refresh_shadows(c, cs);
   hipError_t e2 = hipStreamSynchronize(cs);
   (void)hipFree(save);
   if (rc) return rc;
@@ -1603,6 +1636,7 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
   h.w[HDR_DROP_STEP] = c->drop_step;
   h.w[HDR_DROP_SEED] = c->drop_seed;
   h.w[HDR_XSTEP] = c->xstep;
+  refresh_shadows(c, st);
   if (g_trace) tr_t[1] = now_us();
   // The call's first chunk is a HEAD chunk — 2 steps (1 for a one-step call) behind the set-up kernel, in one graph whose
   // set-up node gets this call's arguments: one host-side launch until the GPU has work, and a short one (a graph
@@ -1874,6 +1908,7 @@ static int actor_forward_impl(iqlhip_ctx* c, const float* states_dev, int64_t ld
   const int total = rows * (int)c->row_ld;
   hipLaunchKernelGGL(iql_pack_states_kernel, dim3((total + 255) / 256), dim3(256), 0, st, c->xb_act, (int)c->row_ld, S,
                      rows, states_dev, (long long)ld_s);
+  refresh_shadows(c, st);
   StepParams p = make_step(c, rows, 1.f / (float)rows);
   p.xb = c->xb_act;
   p.only_inst = 6;
@@ -1930,6 +1965,7 @@ extern "C" int iqlhip_debug_time_kernel(iqlhip_ctx* c, const iqlhip_batch* b, in
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
+  refresh_shadows(c, st);
   for (int w = 0; w < 3; ++w) { launch_fwd(c, p, st); launch_bwd(c, p, st); }
   HIPCHK(hipEventRecord(e0, st));
   for (int i = 0; i < repeat; ++i) {

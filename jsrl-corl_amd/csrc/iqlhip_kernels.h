@@ -30,6 +30,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-by
 #define RT_ROWS 32          // rows per forward / (b) block
 #define CHUNK_ROWS 256      // rows per (a) block chunk
 #define H0_LD 260           // LDS row stride of a [rows][256] tile (16-B aligned, bank-shifted)
+#define H0B_LD 264          // ... of the same tile kept in bf16 (bf16 path): 528-byte rows, 16 rows cover all 64 banks
 #define T64_LD 68           // LDS row stride of a [rows][64] tile
 #define NSPLIT 4            // column slices of the hidden layer per row tile
 #define HEAD_LD 24          // scalar head partials per row: [inst 0..5][ns 0..3]
@@ -57,6 +58,40 @@ __device__ __forceinline__ bf16x8 pack8s(const float (&v)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
   return r;
+}
+// bf16 STORAGE on the bf16 path (round 3): W1 is read from a bf16 shadow of the fp32 master weights (written by the
+// update kernel next to the master, refreshed from it at the start of every library call), and the activations H0 / H1
+// the backward re-reads live in memory as bf16.  Every (lane, element) -> index map is that of the fp32 kernels: a
+// lane's load shrinks from 16 to 8 bytes (4 elements) or from 8 to 4 (2 elements) — half the bytes through the CU's
+// vector-memory pipe, which is what these kernels wait for — and the operands need no conversion any more.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <bool BF16> struct Frag4 { typedef f32x4 type; };
+template <> struct Frag4<true> { typedef bf16x4 type; };
+template <bool BF16> struct Frag2 { typedef f32x2 type; };
+template <> struct Frag2<true> { typedef bf16x2 type; };
+// 4 / 2 consecutive elements at element offset `off` of an array whose element type is float (fp32 path) or __bf16
+// (bf16 path; `base` then is the bf16 array's address carried in a float pointer)
+template <bool BF16> __device__ __forceinline__ typename Frag4<BF16>::type ld4(const float* base, unsigned off) {
+  if constexpr (BF16) return *(const bf16x4*)((const __bf16*)base + off);
+  else return *(const f32x4*)(base + off);
+}
+template <bool BF16> __device__ __forceinline__ typename Frag2<BF16>::type ld2(const float* base, unsigned off) {
+  if constexpr (BF16) return *(const bf16x2*)((const __bf16*)base + off);
+  else return *(const f32x2*)(base + off);
+}
+template <bool BF16> __device__ __forceinline__ void st4(float* base, unsigned off, const f32x4 v) {
+  if constexpr (BF16) {
+    bf16x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (__bf16)v[i];
+    *(bf16x4*)((__bf16*)base + off) = r;
+  } else {
+    *(f32x4*)(base + off) = v;
+  }
+}
+__device__ __forceinline__ bf16x8 cat8(const bf16x4 lo, const bf16x4 hi) {
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 struct DevScratch {
@@ -465,7 +500,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   }
   // (d) this wave's W1 rows (16 output units x 256 k) as MFMA fragments: 64 KiB per block
   int n1 = ns * 64 + wave * 16 + l15;  // hidden-1 unit of this lane
-  f32x4 bw[16];
+  // fp32: 16 fragments of 4 k (k = 16 ks + 4 g + t).  bf16 (np.w1 addresses the bf16 shadow of W1): 8 fragments of 8
+  // CONTIGUOUS k (k = 32 j + 8 g + e) — the bf16 MFMA's native operand, one 16-byte load each; the H0 tile in LDS is
+  // bf16 too and is read with the same map, one ds_read_b128 per operand, no conversion anywhere in layer 1.
+  f32x4 bw[BF16 ? 1 : 16];
+  bf16x8 bwb[BF16 ? 8 : 1];
+  __bf16* H0b = (__bf16*)H0s;          // [32][H0B_LD] (bf16 path: the H0 tile lives here instead of H0s)
 
   xr_store(xr, Xr, n_x);
   const int Dp = (D + 15) & ~15;
@@ -499,7 +539,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   // so that not even the issue time stands in front of layer 0.
   const bool bw_in_l0 = !BF16 && w0_lds;
 #define BW_LOAD(ks_) bw[ks_] = *(const f32x4*)(np.w1 + (unsigned)(n1 * HID + 16 * (ks_) + 4 * g))
-  if (!bw_in_l0) {
+#define BWB_AT(unit_, j_) (*(const bf16x8*)((const __bf16*)np.w1 + (unsigned)((unit_) * HID + 32 * (j_) + 8 * g)))
+  if constexpr (BF16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bwb[j] = BWB_AT(n1, j);
+  } else if (!bw_in_l0) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) BW_LOAD(ks);
   }
@@ -543,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
         asm volatile("" : "+v"(aq[ks][0]), "+v"(aq[ks][1]));
       }
       STAMP(p, 5);
-      if (BF16) {       // (k-steps beyond nks: X side selected to zero above, weight side a clamped finite value)
+      if constexpr (BF16) {       // (k-steps beyond nks: X side selected to zero above, weight side a clamped finite value)
         l0_chunk_bf16(acc, bq, aq);
       } else {
 #pragma unroll
@@ -600,22 +644,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
         }
       };
       auto mm = [&](const float (&bq)[8][4], const float (&aq)[8][2], const int base) {
-        if (BF16) {
+        if constexpr (BF16) {
           l0_chunk_bf16(acc, bq, aq);
-          return;
-        }
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          if (base + ks < nks) {
+          for (int ks = 0; ks < 8; ++ks) {
+            if (base + ks < nks) {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-              acc[0][ct] = MFMA16(bq[ks][ct], aq[ks][0], acc[0][ct]);
-              acc[1][ct] = MFMA16(bq[ks][ct], aq[ks][1], acc[1][ct]);
+              for (int ct = 0; ct < 4; ++ct) {
+                acc[0][ct] = MFMA16(bq[ks][ct], aq[ks][0], acc[0][ct]);
+                acc[1][ct] = MFMA16(bq[ks][ct], aq[ks][1], acc[1][ct]);
+              }
             }
-          }
-          if (base == 0) {    // the W1 fragments, two behind each MFMA group of the first chunk
-            BW_LOAD(2 * ks);
-            BW_LOAD(2 * ks + 1);
+            if (base == 0) {    // the W1 fragments, two behind each MFMA group of the first chunk
+              BW_LOAD(2 * ks);
+              BW_LOAD(2 * ks + 1);
+            }
           }
         }
       };
@@ -661,7 +705,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) h[reg] = ((bits >> reg) & 1u) ? h[reg] * p.drop_scale : 0.f;
         }
-        *(f32x4*)(H0s + (rtile * 16 + l15) * H0_LD + wave * 64 + ct * 16 + 4 * g) = h;
+        if constexpr (BF16) {
+          bf16x4 hb_;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) hb_[reg] = (__bf16)h[reg];
+          *(bf16x4*)(H0b + (rtile * 16 + l15) * H0B_LD + wave * 64 + ct * 16 + 4 * g) = hb_;
+        } else {
+          *(f32x4*)(H0s + (rtile * 16 + l15) * H0_LD + wave * 64 + ct * 16 + 4 * g) = h;
+        }
       }
     }
   }
@@ -686,35 +737,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   }
   // save H0 columns [64*ns, +64) of the trainable instances for the backward pass
   if (slot >= 0) {
-    float* dst = h0g + slot * MB * HID;
     const int rl = tid >> 3;
     const int row = row0 + rl;
     if (row < B) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = ns * 64 + 4 * ((tid & 7) + 8 * j);
-        *(f32x4*)(dst + row * HID + col) = *(const f32x4*)(H0s + rl * H0_LD + col);
+        if constexpr (BF16)
+          *(bf16x4*)((__bf16*)h0g + (unsigned)((slot * MB + row) * HID + col)) = *(const bf16x4*)(H0b + rl * H0B_LD + col);
+        else
+          *(f32x4*)(h0g + (unsigned)((slot * MB + row) * HID + col)) = *(const f32x4*)(H0s + rl * H0_LD + col);
       }
     }
   }
 
+  if (it == 0) STAMP(p, 8);
   // ---- layer 1: this wave computes H1[32][16 units]; A = W1 fragments (m = unit), B = H0 (n = row)
   {
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    if (BF16) {
+    if constexpr (BF16) {
+      // all 16 operand reads of the tile first (one wait), then the 16 MFMAs back to back: written as read -> convert ->
+      // MFMA per k-block the loop ran at one LDS latency + 8 conversions per pair of MFMAs (3.7 k cycles per slice at
+      // 1 024 rows against 256 cycles of matrix work, profiles/r03_stamps_config5_1024_bf16.txt)
+      bf16x8 b0[8], b1[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {     // one bf16 MFMA per 32 k: lane (g) supplies k = 32j + {4g..4g+3, 16+4g..16+4g+3}
-        const bf16x8 a = pack8(bw[2 * j], bw[2 * j + 1]);
-        const bf16x8 b0 = pack8(*(const f32x4*)(H0s + l15 * H0_LD + 32 * j + 4 * g),
-                                *(const f32x4*)(H0s + l15 * H0_LD + 32 * j + 16 + 4 * g));
-        const bf16x8 b1 = pack8(*(const f32x4*)(H0s + (16 + l15) * H0_LD + 32 * j + 4 * g),
-                                *(const f32x4*)(H0s + (16 + l15) * H0_LD + 32 * j + 16 + 4 * g));
-        acc0 = MFMA_BF16(a, b0, acc0);
-        acc1 = MFMA_BF16(a, b1, acc1);
-        if ((j & 1) && more) {      // the next slice's fragments replace the four just used (see below)
+      for (int j = 0; j < 8; ++j) {
+        b0[j] = *(const bf16x8*)(H0b + l15 * H0B_LD + 32 * j + 8 * g);
+        b1[j] = *(const bf16x8*)(H0b + (16 + l15) * H0B_LD + 32 * j + 8 * g);
+      }
 #pragma unroll
-          for (int ks = 2 * j - 2; ks < 2 * j + 2; ++ks)
-            bw[ks] = *(const f32x4*)(np.w1 + (unsigned)((n1 + 64) * HID + 16 * ks + 4 * g));
+      for (int j = 0; j < 8; ++j) {     // one bf16 MFMA per 32 k: lane (g) supplies k = 32 j + 8 g .. + 7 of both operands
+        acc0 = MFMA_BF16(bwb[j], b0[j], acc0);
+        acc1 = MFMA_BF16(bwb[j], b1[j], acc1);
+        if ((j & 1) && more) {      // the next slice's fragments replace the two just used
+          bwb[j - 1] = BWB_AT(n1 + 64, j - 1);
+          bwb[j] = BWB_AT(n1 + 64, j);
         }
       }
     } else {
@@ -736,6 +793,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
         }
       }
     }
+    if (it == 0) STAMP(p, 9);
     f32x4 h0, h1;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -754,7 +812,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
     *(f32x4*)(H1s + l15 * T64_LD + wave * 16 + 4 * g) = h0;
     *(f32x4*)(H1s + (16 + l15) * T64_LD + wave * 16 + 4 * g) = h1;
   }
+  if (it == 0) STAMP(p, 10);
   __syncthreads();
+  if (it == 0) STAMP(p, 11);
   STAMP(p, 3);
   if (more) n1 += 64;
 
@@ -763,11 +823,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
     const int row = row0 + rl;
     const int sub = tid & 7;
     if (slot >= 0 && row < B) {
-      float* dst = h1g + slot * MB * HID;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int cl = 4 * (sub + 8 * j);
-        *(f32x4*)(dst + row * HID + ns * 64 + cl) = *(const f32x4*)(H1s + rl * T64_LD + cl);
+        st4<BF16>(h1g, (unsigned)((slot * MB + row) * HID + ns * 64 + cl), *(const f32x4*)(H1s + rl * T64_LD + cl));
       }
     }
     // ---- head partial sums over this block's 64 hidden-1 units (slice 0 also adds the bias)
@@ -816,8 +875,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
       }
     }
   }
+  if (it == 0) STAMP(p, 12);
   if (!more) break;
   __syncthreads();      // every thread is done with this slice's H1s / W2s
+  if (it == 0) STAMP(p, 13);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int e = tid + 256 * q;
@@ -1040,8 +1101,10 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   const int Dp = (D + 15) & ~15;      // 16 or 32
   const int DYLD = Dp + 4;            // dY row stride in LDS: 16-B aligned rows (float4 reads of a row's dims)
   const float* w2 = np.w2;
-  const float* H1g = p.sc.h1 + net * MB * HID;
-  const float* H0g = p.sc.h0 + net * MB * HID;
+  // (bf16 path: H0 / H1 are stored as bf16 — the same element offsets, half the bytes; the pointers below then carry
+  //  the bf16 arrays' addresses and are only ever dereferenced through ld4 / ld2)
+  const float* H1g = BF16 ? (const float*)((const __bf16*)p.sc.h1 + net * MB * HID) : p.sc.h1 + net * MB * HID;
+  const float* H0g = BF16 ? (const float*)((const __bf16*)p.sc.h0 + net * MB * HID) : p.sc.h0 + net * MB * HID;
   // dropout: the saved activations are post-dropout, so (h > 0) already encodes relu AND keep; the chain
   // rule only adds the 1/(1-p) multiplier
   const float dscale = (net == IQLHIP_NET_PI && p.drop_bits != nullptr) ? p.drop_scale : 1.f;
@@ -1130,13 +1193,13 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // comes out of an MFMA (wide heads, below), so that result feeds the dW1 MFMA without a shuffle.  Rows >= B are
     // clamped to a valid row: their dY is 0, so they contribute nothing.
 #define AROW(ks) (64 * wave + 16 * ((ks) >> 2) + 4 * g + ((ks) & 3))
-    f32x2 hh[16];
-    f32x4 bb[16];
+    typename Frag2<BF16>::type hh[16];
+    typename Frag4<BF16>::type bb[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const unsigned row = (unsigned)BROW(cbase + AROW(ks));
-      hh[ks] = *(const f32x2*)(H1g + (row * (unsigned)HID + (unsigned)(j0 + 2 * l15)));
-      bb[ks] = *(const f32x4*)(H0g + (row * (unsigned)HID + (unsigned)(i0 + 4 * l15)));
+      hh[ks] = ld2<BF16>(H1g, row * (unsigned)HID + (unsigned)(j0 + 2 * l15));
+      bb[ks] = ld4<BF16>(H0g, row * (unsigned)HID + (unsigned)(i0 + 4 * l15));
     }
     STAMP(p, 10);
     // ---- dY for the 256 rows of the chunk (thread = row)
@@ -1313,11 +1376,11 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const float dy = dYs[AROW(ks) * DYA];
-        av[ks][0] = (hh[ks][0] > 0.f) ? dy * w2a * dscale : 0.f;
-        av[ks][1] = (hh[ks][1] > 0.f) ? dy * w2b * dscale : 0.f;
+        av[ks][0] = ((float)hh[ks][0] > 0.f) ? dy * w2a * dscale : 0.f;
+        av[ks][1] = ((float)hh[ks][1] > 0.f) ? dy * w2b * dscale : 0.f;
         if (do_dw2) {
-          dw2a[0] = fmaf(dy, hh[ks][0], dw2a[0]);
-          dw2a[1] = fmaf(dy, hh[ks][1], dw2a[1]);
+          dw2a[0] = fmaf(dy, (float)hh[ks][0], dw2a[0]);
+          dw2a[1] = fmaf(dy, (float)hh[ks][1], dw2a[1]);
         }
       }
     } else {
@@ -1335,8 +1398,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       else dh1_mfma<8>(pre, dYs, W2s, DYA, wave, g, l15);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        av[ks][0] = (hh[ks][0] > 0.f) ? pre[ks >> 2][0][ks & 3] * dscale : 0.f;
-        av[ks][1] = (hh[ks][1] > 0.f) ? pre[ks >> 2][1][ks & 3] * dscale : 0.f;
+        av[ks][0] = ((float)hh[ks][0] > 0.f) ? pre[ks >> 2][0][ks & 3] * dscale : 0.f;
+        av[ks][1] = ((float)hh[ks][1] > 0.f) ? pre[ks >> 2][1][ks & 3] * dscale : 0.f;
       }
     }
     if (do_db1) {
@@ -1350,7 +1413,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (BF16) {
+    if constexpr (BF16) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {       // rows (k) 8q..8q+7 of this lane's 16
         bf16x8 A[2], Bv[4];
@@ -1362,11 +1425,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           A[ta] = pack8s(t8);
         }
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
-          float t8[8];
+        for (int tb = 0; tb < 4; ++tb) {      // (H0 arrives as bf16: the operand is assembled, not converted)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) t8[e] = bb[8 * q + e][tb];
-          Bv[tb] = pack8s(t8);
+          for (int e = 0; e < 8; ++e) Bv[tb][e] = bb[8 * q + e][tb];
         }
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta)
@@ -1396,7 +1457,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int ks = 0; ks < 16; ++ks) ad[ks] = dYs[AROW(ks) * DYA + l15];
       float hsel[16];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) hsel[ks] = tb_own ? hh[ks][1] : hh[ks][0];
+      for (int ks = 0; ks < 16; ++ks) hsel[ks] = tb_own ? (float)hh[ks][1] : (float)hh[ks][0];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) acc2[0][0] = MFMA16(ad[ks], hsel[ks], acc2[0][0]);
       if (ndt > 1) {
@@ -1498,7 +1559,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     const int xoff = 0;                   // trainable nets read s or [s|a]: both start at column 0
     const float* w1 = np.w1;
 
-    float* dH1s = smem;                              // [32][H0_LD]
+    float* dH1s = smem;                              // [32][H0_LD]  (bf16 path: the same tile as bf16 [32][H0B_LD], below)
+    __bf16* dH1b = (__bf16*)smem;
     float* red = dH1s + RT_ROWS * H0_LD;             // [4][32][T64_LD]
     float* dH0s = red + 4 * 32 * T64_LD;             // [32][T64_LD]
     float* dYs = dH0s + RT_ROWS * T64_LD;            // [32][DYLD]
@@ -1548,24 +1610,24 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int j = 0; j < 8; ++j) w2v8[j] = *(const f32x4*)(w2 + min(j, D - 1) * HID + 4 * j4);
     }
     // H1 tile [32][256] as float4 f = tid + 256q: row f>>6, cols 4*(f&63)
-    f32x4 h1v[8];
+    typename Frag4<BF16>::type h1v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int f = tid + 256 * q;
       const unsigned row = (unsigned)BROW(row0 + (f >> 6));   // rows >= B: dY = 0 -> dH1 = 0
-      h1v[q] = *(const f32x4*)(H1g + (row * (unsigned)HID + (unsigned)(4 * (f & 63))));
+      h1v[q] = ld4<BF16>(H1g, row * (unsigned)HID + (unsigned)(4 * (f & 63)));
     }
     // W1 fragments: k = j in [64*wave, +64), n = i0 + 4*l15 + t — requested after the dY barrier (below): 16 KiB
     // per wave of fragment-shaped loads take ~1.5 k cycles of the CU's vector-memory pipe to issue, which in front of
     // the loss arithmetic only delayed it; issued there they stream in under the dH1 tile phase
-    f32x4 bw[16];
+    typename Frag4<BF16>::type bw[16];      // (bf16 path: np.w1 addresses the bf16 shadow of W1)
     // H0 mask slice [32][64] as float4 f = tid + 256q: row f>>4, cols i0 + 4*(f&15)
-    f32x4 h0v[2];
+    typename Frag4<BF16>::type h0v[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int f = tid + 256 * q;
       const unsigned row = (unsigned)BROW(row0 + (f >> 4));
-      h0v[q] = *(const f32x4*)(H0g + (row * (unsigned)HID + (unsigned)(i0 + 4 * (f & 15))));
+      h0v[q] = ld4<BF16>(H0g, row * (unsigned)HID + (unsigned)(i0 + 4 * (f & 15)));
     }
     const int n_x = RT_ROWS * ld / 4;
     const int x_last = B * ld / 4 - 1;
@@ -1604,7 +1666,10 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     STAMP(p, 5);
     // (requested two at a time between the row groups of the dH1 tile below: the four waves' 64 KB take ~1 k cycles of
     //  the CU's 64 B/clk fill path, which the tile's arithmetic covers instead of waiting behind it)
-#define BWB_LOAD(ks_) bw[ks_] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * (ks_) + g) * HID + i0 + 4 * l15))
+    // W1 row (= k index j of dH0 = dH1 . W1) of fragment ks: fp32 k = 4 ks + g (+ 64 wave); bf16: the bf16 MFMA's native map,
+    // 8 CONTIGUOUS k per lane group — k = 32 (ks >> 3) + 8 g + (ks & 7) — so that the dH1 operand is ONE 16-byte LDS read
+#define BWB_ROW(ks_) (BF16 ? (64 * wave + 32 * ((ks_) >> 3) + 8 * g + ((ks_) & 7)) : (64 * wave + 4 * (ks_) + g))
+#define BWB_LOAD(ks_) bw[ks_] = ld4<BF16>(w1, (unsigned)(BWB_ROW(ks_) * HID + i0 + 4 * l15))
 
     // dH1s[r][j] = (sum_dd dY[r][dd] W2[dd][j]) * (H1[r][j] > 0)
     if (D > 8) {
@@ -1642,8 +1707,15 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         const int rl = (tid + 256 * q) >> 6;
         f32x4 out;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? sacc[q][e] * dscale : 0.f;
-        *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+        for (int e = 0; e < 4; ++e) out[e] = ((float)h1v[q][e] > 0.f) ? sacc[q][e] * dscale : 0.f;
+        if constexpr (BF16) {
+          bf16x4 ob_;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ob_[e] = (__bf16)out[e];
+          *(bf16x4*)(dH1b + rl * H0B_LD + 4 * j4) = ob_;
+        } else {
+          *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+        }
         BWB_LOAD(2 * q);
         BWB_LOAD(2 * q + 1);
       }
@@ -1666,8 +1738,15 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         }
         f32x4 out;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = (h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
-        *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+        for (int e = 0; e < 4; ++e) out[e] = ((float)h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
+        if constexpr (BF16) {
+          bf16x4 ob_;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ob_[e] = (__bf16)out[e];
+          *(bf16x4*)(dH1b + rl * H0B_LD + 4 * j4) = ob_;
+        } else {
+          *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
+        }
         BWB_LOAD(2 * q);
         BWB_LOAD(2 * q + 1);
       }
@@ -1683,7 +1762,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // requested into the registers this slice's MFMAs have just consumed, its H0 mask under the MFMA phase.
     for (int itn = 0;; ++itn) {
     const bool more = MULTI && (itn + 1 < (1 << bsl2));
-    f32x4 h0n[2] = {h0v[0], h0v[1]};
+    typename Frag4<BF16>::type h0n[2] = {h0v[0], h0v[1]};
 
     // dH0 partial over this wave's 64 j's: [32 rows][64 cols]
     {
@@ -1692,30 +1771,23 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (BF16) {
+      if constexpr (BF16) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {     // k = j index: 64w + 4(8q+e) + g, e = 0..7
-          float t0[8], t1[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int kk = 64 * wave + 4 * (8 * q + e) + g;
-            t0[e] = dH1s[l15 * H0_LD + kk];
-            t1[e] = dH1s[(16 + l15) * H0_LD + kk];
-          }
-          const bf16x8 A0 = pack8s(t0), A1 = pack8s(t1);
+        for (int q = 0; q < 2; ++q) {     // k = j index: 64w + 32q + 8g + e, e = 0..7 — one 16-byte read per operand
+          const bf16x8 A0 = *(const bf16x8*)(dH1b + l15 * H0B_LD + 64 * wave + 32 * q + 8 * g);
+          const bf16x8 A1 = *(const bf16x8*)(dH1b + (16 + l15) * H0B_LD + 64 * wave + 32 * q + 8 * g);
 #pragma unroll
           for (int tb = 0; tb < 4; ++tb) {
-            float t8[8];
+            bf16x8 Bv;                        // (the W1 shadow arrives as bf16: assembled, not converted)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t8[e] = bw[8 * q + e][tb];
-            const bf16x8 Bv = pack8s(t8);
+            for (int e = 0; e < 8; ++e) Bv[e] = bw[8 * q + e][tb];
             acc[0][tb] = MFMA_BF16(A0, Bv, acc[0][tb]);
             acc[1][tb] = MFMA_BF16(A1, Bv, acc[1][tb]);
           }
           if (more) {
 #pragma unroll
             for (int ks = 8 * q; ks < 8 * q + 8; ++ks)
-              bw[ks] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * ks + g) * HID + i0 + 64 + 4 * l15));
+              bw[ks] = ld4<BF16>(w1, (unsigned)(BWB_ROW(ks) * HID + i0 + 64 + 4 * l15));
           }
         }
       } else {
@@ -1732,7 +1804,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           if ((ks & 3) == 3 && more) {
 #pragma unroll
             for (int k2 = ks - 3; k2 <= ks; ++k2)
-              bw[k2] = *(const f32x4*)(w1 + (unsigned)((64 * wave + 4 * k2 + g) * HID + i0 + 64 + 4 * l15));
+              bw[k2] = ld4<BF16>(w1, (unsigned)((64 * wave + 4 * k2 + g) * HID + i0 + 64 + 4 * l15));
           }
         }
       }
@@ -1741,7 +1813,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         for (int q = 0; q < 2; ++q) {
           const int f = tid + 256 * q;
           const unsigned row = (unsigned)BROW(row0 + (f >> 4));
-          h0n[q] = *(const f32x4*)(H0g + (row * (unsigned)HID + (unsigned)(i0 + 64 + 4 * (f & 15))));
+          h0n[q] = ld4<BF16>(H0g, row * (unsigned)HID + (unsigned)(i0 + 64 + 4 * (f & 15)));
         }
       }
       float* myred = red + wave * 32 * T64_LD;
@@ -1767,7 +1839,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + w * 32 * T64_LD + rl * T64_LD + 4 * i4);
       f32x4 out;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[e] = (h0v[q][e] > 0.f) ? s[e] * dscale : 0.f;   // rows >= B carry s = 0
+      for (int e = 0; e < 4; ++e) out[e] = ((float)h0v[q][e] > 0.f) ? s[e] * dscale : 0.f;   // rows >= B carry s = 0
       *(f32x4*)(dH0s + rl * T64_LD + 4 * i4) = out;
     }
     __syncthreads();
@@ -1893,6 +1965,10 @@ struct UpdParams {
   // a caller can observe of the step is ordered by the stream as before.  Null elsewhere.
   unsigned long long* done_flag;
   unsigned long long done_val;
+  // bf16 path: bf16 shadows of the parameter and target arenas (same element offsets), written next to the fp32
+  // masters so that the following forward / backward read their W1 fragments at half the bytes; null on the fp32 path
+  __bf16* wsh;
+  __bf16* tsh;
 };
 
 __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
@@ -2002,6 +2078,15 @@ __global__ __launch_bounds__(256) void iql_call_setup_kernel(unsigned long long*
   if (drop_dst)
     dropmask_words(drop_dst, drop_words, drop_thresh, h.w[HDR_DROP_SEED], h.w[HDR_DROP_STEP],
                    ((int)gridDim.x - 1 - (int)blockIdx.x) * 256 + (int)threadIdx.x, (int)gridDim.x * 256);
+}
+
+// bf16 shadows rebuilt from the fp32 masters (start of every library call on the bf16 path: the caller owns the
+// masters and may have written them through its own tensors since the last update kernel ran).
+__global__ __launch_bounds__(256) void iql_shadow_refresh_kernel(const float* params, const float* target, __bf16* wsh,
+                                                                 __bf16* tsh, long long n_params, long long n_target) {
+  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e < n_params) st4<true>((float*)wsh, (unsigned)e, *(const f32x4*)(params + e));
+  if (e < n_target) st4<true>((float*)tsh, (unsigned)e, *(const f32x4*)(target + e));
 }
 
 // Diagnostic (tools/gpu_call_overhead.py): a host-mapped word that says "everything queued before me has run".
@@ -2221,10 +2306,12 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     *(f32x4*)(u.m + e) = m;
     *(f32x4*)(u.v + e) = v;
     *(f32x4*)(u.params + e) = pw;
+    if (u.wsh) st4<true>((float*)u.wsh, (unsigned)e, pw);
     if (is_q) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] = fmaf(u.tau, pw[k], u.one_minus_tau * t[k]);
       *(f32x4*)tp = t;
+      if (u.tsh) st4<true>((float*)u.tsh, (unsigned)(e - u.L.target_src), t);
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {

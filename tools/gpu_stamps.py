@@ -96,7 +96,8 @@ def xcd_spans(name, blocks, last):
 n_rt = (B + 31) // 32
 fsl2 = int(os.environ.get("IQLHIP_FWD_SPB_L2", 0 if 8 * n_rt * 4 <= 256 else (1 if 8 * n_rt * 2 <= 256 else 2)))
 fwd_blocks = np.arange(8 * n_rt * (4 >> fsl2))
-report("fwd prologue", fwd_blocks, [(8, "stamp cost"), (9, "issue all loads"), (10, "wait X rows + LDS store"), (11, "wait W2/W0 + LDS stores"), (1, "barrier")])
+report("fwd slice 0 (after the layer-0 barrier)", fwd_blocks, [(2, "(layer-0 barrier)"), (8, "H0 save (+ next slice's W2/b1 requests)"), (9, "layer-1 operand reads + MFMAs"), (10, "epilogue + H1 tile write"), (11, "barrier"),
+                                                              (12, "H1 save + head partials"), (13, "barrier before the next slice")])
 report("fwd", fwd_blocks, [(1, "prefetch+gather"), (5, "L0: LDS operand reads"), (6, "L0: MFMAs"), (7, "L0: epilogue + H0 writes"), (2, "L0: barrier"), (3, "H0 save + layer1"), (4, "H1 save + head")])
 n_chunk = (B + 255) // 256
 # launch_bwd's layout: beyond two rounds of the chip the (b) blocks walk 4 column slices and take the FIRST block indices
