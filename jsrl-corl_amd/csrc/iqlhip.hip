@@ -688,7 +688,8 @@ static void launch_bwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t 
   StepParams p = p_in;
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   const int n_chunk = (p.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
-  const int l2 = bwd_spb_l2(c, n_chunk, n_rt);
+  int l2 = bwd_spb_l2(c, n_chunk, n_rt);
+  if (c->precision == 1 && l2 > 0) l2 = 2;      // bf16, large batches: a (b) block takes the whole row tile in one pass
   const int per_net = 32 * n_chunk + (4 >> l2) * n_rt;
   // multi-round launches: this many of the policy's dW1-tile blocks run at the ends of the scalar nets' XCD queues
   // (iql_bwd_kernel); share of its 32 n_chunk tiles tuned on obs 17 / act 6 and obs 39 / act 28 (profiles/r02_slices_per_block.txt)

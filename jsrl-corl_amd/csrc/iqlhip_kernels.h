@@ -1620,7 +1620,11 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // W1 fragments: k = j in [64*wave, +64), n = i0 + 4*l15 + t — requested after the dY barrier (below): 16 KiB
     // per wave of fragment-shaped loads take ~1.5 k cycles of the CU's vector-memory pipe to issue, which in front of
     // the loss arithmetic only delayed it; issued there they stream in under the dH1 tile phase
-    typename Frag4<BF16>::type bw[16];      // (bf16 path: np.w1 addresses the bf16 shadow of W1)
+    // FULLB (bf16, large batches): the waves split the COLUMNS (64 each) instead of the k range — no cross-wave
+    // reduction — and walk all 256 k in 8 blocks of 32; ALL 64 fragments of the wave (128 registers) are requested during
+    // the dH1 tile phase: fetched two k-blocks ahead the product waited ~1 k cycles per k-block for them
+    constexpr bool FULLB = BF16 && MULTI;
+    typename Frag4<BF16>::type bw[FULLB ? 64 : 16];      // (bf16 path: np.w1 addresses the bf16 shadow of W1)
     // H0 mask slice [32][64] as float4 f = tid + 256q: row f>>4, cols i0 + 4*(f&15)
     typename Frag4<BF16>::type h0v[2];
 #pragma unroll
@@ -1667,9 +1671,11 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // (requested two at a time between the row groups of the dH1 tile below: the four waves' 64 KB take ~1 k cycles of
     //  the CU's 64 B/clk fill path, which the tile's arithmetic covers instead of waiting behind it)
     // W1 row (= k index j of dH0 = dH1 . W1) of fragment ks: fp32 k = 4 ks + g (+ 64 wave); bf16: the bf16 MFMA's native map,
-    // 8 CONTIGUOUS k per lane group — k = 32 (ks >> 3) + 8 g + (ks & 7) — so that the dH1 operand is ONE 16-byte LDS read
-#define BWB_ROW(ks_) (BF16 ? (64 * wave + 32 * ((ks_) >> 3) + 8 * g + ((ks_) & 7)) : (64 * wave + 4 * (ks_) + g))
-#define BWB_LOAD(ks_) bw[ks_] = ld4<BF16>(w1, (unsigned)(BWB_ROW(ks_) * HID + i0 + 4 * l15))
+    // 8 CONTIGUOUS k per lane group — k = 32 (ks >> 3) + 8 g + (ks & 7) — so that the dH1 operand is ONE 16-byte LDS read.
+    // FULLB: fragment ks = 8 kb + e of k-block kb: row 32 kb + 8 g + e, columns 64 wave + 4 l15 ..
+#define BWB_ROW(ks_) (FULLB ? (32 * ((ks_) >> 3) + 8 * g + ((ks_) & 7)) : (BF16 ? (64 * wave + 32 * ((ks_) >> 3) + 8 * g + ((ks_) & 7)) : (64 * wave + 4 * (ks_) + g)))
+#define BWB_COL (FULLB ? (64 * wave + 4 * l15) : (i0 + 4 * l15))
+#define BWB_LOAD(ks_) bw[ks_] = ld4<BF16>(w1, (unsigned)(BWB_ROW(ks_) * HID + BWB_COL))
 
     // dH1s[r][j] = (sum_dd dY[r][dd] W2[dd][j]) * (H1[r][j] > 0)
     if (D > 8) {
@@ -1716,8 +1722,13 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         } else {
           *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
         }
-        BWB_LOAD(2 * q);
-        BWB_LOAD(2 * q + 1);
+        if constexpr (FULLB) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) BWB_LOAD(8 * q + e);
+        } else {
+          BWB_LOAD(2 * q);
+          BWB_LOAD(2 * q + 1);
+        }
       }
     } else {
 #pragma unroll
@@ -1747,12 +1758,120 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         } else {
           *(f32x4*)(dH1s + rl * H0_LD + 4 * j4) = out;
         }
-        BWB_LOAD(2 * q);
-        BWB_LOAD(2 * q + 1);
+        if constexpr (FULLB) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) BWB_LOAD(8 * q + e);
+        } else {
+          BWB_LOAD(2 * q);
+          BWB_LOAD(2 * q + 1);
+        }
       }
     }
     __syncthreads();
     STAMP(p, 6);
+    if constexpr (FULLB) {
+      // ===== bf16, large batches: the whole row tile in one pass (host: 4 slices per (b) block, i0 = 0).  Per slice
+      // the old structure paid three barriers, a cross-wave reduction through LDS and a dozen dependent LDS round
+      // trips for ~300 cycles of matrix work (8 k cycles per slice at 1 024 rows, profiles/r03_stamps_config5_1024_bf16.txt).
+      // Here wave w owns columns [64 w, 64 w + 64) of dH0 = dH1 . W1 over ALL 256 k (8 k-blocks of 32, the W1 shadow's
+      // fragments double-buffered in registers), masks them in registers, parks them TRANSPOSED (bf16 [col][row]) for the
+      // dW0 product — whose operands then are one 16-byte LDS read each — and stores its 64 rows of [dW0 | db0].
+      typename Frag4<true>::type hm[2][4];          // H0 mask in accumulator layout: rows 16 rt + 4 g + reg, cols 64 w + 4 l15 ..
+#pragma unroll
+      for (int rtl = 0; rtl < 2; ++rtl)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const unsigned row = (unsigned)BROW(row0 + 16 * rtl + 4 * g + reg);
+          hm[rtl][reg] = ld4<true>(H0g, row * (unsigned)HID + (unsigned)(64 * wave + 4 * l15));
+        }
+      f32x4 xr[XR_MAX_F4];
+      xr_load(xr, p.xb, row0 * ld / 4, n_x, x_last);
+      bf16x8 Ad[2][8];
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        Ad[0][kb] = *(const bf16x8*)(dH1b + l15 * H0B_LD + 32 * kb + 8 * g);
+        Ad[1][kb] = *(const bf16x8*)(dH1b + (16 + l15) * H0B_LD + 32 * kb + 8 * g);
+      }
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          bf16x8 Bv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) Bv[e] = bw[8 * kb + e][tb];
+          acc[0][tb] = MFMA_BF16(Ad[0][kb], Bv, acc[0][tb]);
+          acc[1][tb] = MFMA_BF16(Ad[1][kb], Bv, acc[1][tb]);
+        }
+      }
+      STAMP(p, 7);
+      constexpr int TLD = 40;                         // row stride of the transposed tile: 80 bytes, conflict-free 16-byte reads
+      __bf16* dH0T = (__bf16*)red;                    // [256][TLD]
+#pragma unroll
+      for (int rtl = 0; rtl < 2; ++rtl)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          bf16x4 o;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg)
+            o[reg] = (__bf16)(((float)hm[rtl][reg][tb] > 0.f) ? acc[rtl][tb][reg] * dscale : 0.f);    // rows >= B carry 0
+          *(bf16x4*)(dH0T + (64 * wave + 4 * l15 + tb) * TLD + 16 * rtl + 4 * g) = o;
+        }
+      xr_store(xr, Xr, n_x);
+      __syncthreads();
+      STAMP(p, 8);
+      // [dW0 | db0][i][kc] = sum_r dH0[r][i] [X | 1][r][kc]: A = [X | 1] (m = kc, k = row 8 g + e), B = dH0T (n = i, k = row)
+      const int k1 = k0 + 1;
+      const int nct = (k1 + 15) >> 4;
+      bf16x8 Ax[9];
+#pragma unroll
+      for (int ct = 0; ct < 9; ++ct) {
+        if (ct < nct) {
+          const int kc = 16 * ct + l15;
+          const int kcc = min(kc, k0 - 1);
+          float a8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xa = Xr[(8 * g + e) * ld + xoff + kcc];
+            a8[e] = (kc < k0) ? xa : ((kc == k0) ? 1.f : 0.f);      // ones column -> db0
+          }
+          Ax[ct] = pack8s(a8);
+        }
+      }
+      float* slabB = p.sc.slab_b + p.sc.slab_b_off[net] + rt * (HID * k0 + HID);
+      float* dstB = slabB + HID * k0;
+      STAMP(p, 12);
+#pragma unroll
+      for (int itl = 0; itl < 4; ++itl) {
+        const int il = 64 * wave + 16 * itl + l15;
+        const bf16x8 Bd = *(const bf16x8*)(dH0T + il * TLD + 8 * g);
+#pragma unroll
+        for (int ct = 0; ct < 9; ++ct) {
+          if (ct < nct) {
+            const f32x4 r4 = MFMA_BF16(Ax[ct], Bd, ((f32x4){0.f, 0.f, 0.f, 0.f}));
+            const int kc0 = 16 * ct + 4 * g;
+            if (kc0 + 3 < k0) {
+              *(f32x4u*)(slabB + (unsigned)(il * k0 + kc0)) = r4;
+            } else {
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                const int kc = kc0 + reg;
+                if (kc < k0) slabB[(unsigned)(il * k0 + kc)] = r4[reg];
+                else if (kc == k0) dstB[il] = r4[reg];
+              }
+            }
+          }
+        }
+      }
+      STAMP(p, 9);
+      RT_STAMP(p, 14, rt_entry_);
+      RT_STAMP(p, 15, iql_realtime());
+      return;
+    }
     // the 32 packed rows, needed last (dW0): issued only now — the H1 / W2 registers are free again, the loads
     // queue behind the W1 fragments (so waiting for those does not wait for these) and the MFMA phase hides them
     f32x4 xr[XR_MAX_F4];

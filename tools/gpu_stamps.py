@@ -116,6 +116,8 @@ b_blocks = bw[(local >= 32 * n_chunk) & (local < per_net)]
 LAB_A = [(10, "issue loads"), (5, "pi: row loads + w"), (6, "pi: wS barrier"), (7, "pi: (row,dim) math"), (11, "wait heads + dY (rest)"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
          (4, "reduce + store (+extras)")]
 LAB_B = [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"), (8, "reduce+mask"), (12, "dW0: LDS reads + MFMA"), (13, "dW0: stage T + barrier"), (9, "dW0: copy out")]
+if os.environ.get("PRECISION") == "bf16" and bsl2 > 0:      # the full-width bf16 tail of the (b) blocks
+    LAB_B = [(5, "loads + dY(32)"), (6, "dH1 tile + barrier"), (7, "dH0: 64 MFMAs over all k"), (8, "mask + transposed tile + barrier"), (12, "dW0 operands (X side)"), (9, "dW0 MFMAs + stores")]
 if os.environ.get("PER_IT"):
     for n, nm in ((0, "V"), (3, "PI")):
         for itv in range(4):
