@@ -704,7 +704,15 @@ static void launch_bwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t 
   const dim3 grid(8 * ((per_net + 1) / 2 + (n_don + 5) / 6));
   const bool full = (p.rows % CHUNK_ROWS) == 0;      // every tile of every block lies inside the batch: no clamps
   const bool bf = c->precision == 1, multi = l2 > 0;
-#define BWD_LAUNCH(BF, FU, MU) hipLaunchKernelGGL((iql_bwd_kernel<BF, FU, MU>), grid, dim3(256), c->lds_bwd, st, p, n_chunk, n_rt)
+  // the leading arguments are preloaded into SGPRs with each wave (build: -mllvm -amdgpu-kernarg-preload-count=14): what a
+  // block needs to issue its first loads, see iql_bwd_kernel
+  const float* q_heads = p.sc.heads; const float* q_xb = p.xb; const float* q_h1 = p.sc.h1; const float* q_h0 = p.sc.h0;
+  const float* q_params = c->params;
+  const unsigned q_dims = (unsigned)p.S | ((unsigned)p.A << 8) | ((unsigned)p.policy << 14);
+  const unsigned q_ldB = (unsigned)p.ld | ((unsigned)p.rows << 10);
+  const unsigned q_mbc = (unsigned)p.sc.max_batch | ((unsigned)n_chunk << 16);
+  const unsigned q_rts = (unsigned)n_rt | ((unsigned)p.spb_l2 << 10);
+#define BWD_LAUNCH(BF, FU, MU) hipLaunchKernelGGL((iql_bwd_kernel<BF, FU, MU>), grid, dim3(256), c->lds_bwd, st, q_heads, q_xb, q_h1, q_h0, q_params, q_dims, q_ldB, q_mbc, q_rts, p)
   if (multi) {
     if (bf) { if (full) BWD_LAUNCH(true, true, true); else BWD_LAUNCH(true, false, true); }
     else    { if (full) BWD_LAUNCH(false, true, true); else BWD_LAUNCH(false, false, true); }

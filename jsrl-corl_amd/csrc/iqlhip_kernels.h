@@ -918,6 +918,16 @@ __device__ __forceinline__ void row_issue(const StepParams& p, int row, RowIn& i
   in.d = xb[ox + 1u];
 }
 
+// (the same with every input an explicit argument: the backward passes values that arrive preloaded in SGPRs)
+__device__ __forceinline__ void row_issue_hot(const float* heads, const float* xb, int ld, int S, int A, int row, RowIn& in) {
+  const unsigned o = (unsigned)row * (unsigned)HEAD_LD;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) in.h[i] = *(const f32x4*)(heads + (o + 4u * i));
+  const unsigned ox = (unsigned)row * (unsigned)ld + (unsigned)(2 * S + A);
+  in.r = xb[ox];
+  in.d = xb[ox + 1u];
+}
+
 __device__ __forceinline__ float sum4(const f32x4 v) { return ((v[0] + v[1]) + v[2]) + v[3]; }
 
 // tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware transcendentals: exp2 (v_exp_f32, 1 ulp) of 2x*log2(e) and
@@ -941,6 +951,21 @@ struct PiConst { float ls, ivar; };
 __device__ __forceinline__ float pi_ls_issue(const StepParams& p) {
   const float* src = (p.policy == IQLHIP_POLICY_GAUSSIAN) ? p.log_std : p.xb;      // any valid address when unused
   return src[min((int)(threadIdx.x & 63), p.A - 1)];
+}
+__device__ __forceinline__ float pi_ls_issue_hot(const float* log_std, const float* xb, int policy, int A) {
+  const float* src = (policy == IQLHIP_POLICY_GAUSSIAN) ? log_std : xb;      // any valid address when unused
+  return src[min((int)(threadIdx.x & 63), A - 1)];
+}
+__device__ __forceinline__ PiConst pi_consts_hot(const StepParams& p, int policy, int net, float lsr) {
+  PiConst c;
+  c.ls = 0.f;
+  c.ivar = 1.f;
+  if (net == IQLHIP_NET_PI && policy == IQLHIP_POLICY_GAUSSIAN) {
+    c.ls = fminf(fmaxf(lsr, p.hy.log_std_min), p.hy.log_std_max);
+    const float sig = expf(c.ls);
+    c.ivar = 1.f / (sig * sig);
+  }
+  return c;
 }
 __device__ __forceinline__ PiConst pi_consts(const StepParams& p, int net, float lsr) {
   PiConst c;
@@ -1035,26 +1060,59 @@ __device__ __forceinline__ void pi_items8(const f32x4 (&hv)[8], const float (&ac
 // FULL: every row of every block's tile is a row of the batch (B % 256 == 0; the host selects the instantiation):
 // no row index is clamped, so consecutive loads differ by compile-time constants.
 #define BROW(r) (FULL ? (r) : min((r), B - 1))
+// Kernel-argument PRELOAD (library built with -mllvm -amdgpu-kernarg-preload-count=14): the first 14 dwords of the
+// explicit arguments arrive in SGPRs with the wave instead of through s_load from the freshly written argument block
+// (measured 450-700 cycles until a field of the by-value StepParams is usable, 40 with preloading:
+// profiles/r03_kernarg_latency_microbench.txt).  They are exactly what the block needs to ISSUE its first loads — the
+// four scratch / batch pointers, the parameter arena (W2 and log_std addresses follow from the dims: arena_off below
+// restates iqlhip_arena_layout) and the dims; everything else still comes from `p`, whose fetch now overlaps them.
+//   q_dims = S | A << 8 | policy << 14      q_ldB = ld | rows << 10      q_mbc = max_batch | n_chunk << 16
+//   q_rts  = n_rt | spb_l2 word << 10
+struct ArenaOff { unsigned w0, b0, b1, w2, b2, log_std; int k0, d; };
+__device__ __forceinline__ ArenaOff arena_off(int net, int S, int A, bool gauss) {
+  auto seg = [&](int k, int d, bool ls) -> unsigned {
+    const unsigned n = 65536u + 256u * (unsigned)k + 512u + 256u * (unsigned)d + (((unsigned)d + 3u) & ~3u) + (ls ? (((unsigned)A + 3u) & ~3u) : 0u);
+    return (n + 63u) & ~63u;
+  };
+  const unsigned sV = seg(S, 1, false), sQ = seg(S + A, 1, false);
+  const unsigned begin = (net == IQLHIP_NET_V) ? 0u : ((net == IQLHIP_NET_Q1) ? sV : ((net == IQLHIP_NET_Q2) ? sV + sQ : sV + 2u * sQ));
+  ArenaOff o;
+  o.k0 = (net == IQLHIP_NET_Q1 || net == IQLHIP_NET_Q2) ? S + A : S;
+  o.d = (net == IQLHIP_NET_PI) ? A : 1;
+  o.w0 = begin + 65536u;
+  o.b0 = o.w0 + 256u * (unsigned)o.k0;
+  o.b1 = o.b0 + 256u;
+  o.w2 = o.b1 + 256u;
+  o.b2 = o.w2 + 256u * (unsigned)o.d;
+  o.log_std = o.b2 + (((unsigned)o.d + 3u) & ~3u);
+  return o;
+}
 template <bool BF16, bool FULL, bool MULTI>
-__global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk, int n_rt) {
+__global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, const float* q_xb, const float* q_h1, const float* q_h0,
+                                                      const float* q_params, unsigned q_dims, unsigned q_ldB, unsigned q_mbc,
+                                                      unsigned q_rts, StepParams p) {
   RT_ENTRY();
   const int bid = blockIdx.x;
   const int x = bid & 7;
-  // (destinations of the un-waited prefetch loads below: kept allocated until the asm that waits for them, behind the
-  //  pinned argument batch — hipcc does not track scalar loads inside inline asm and could otherwise hand the registers
-  //  to a live value before the loads have written them)
-  unsigned kpf[8];
-  {
-    // Touch every 64-byte line of the kernel-argument block this kernel reads, NOW and without waiting: hipcc fetches
-    // the arguments in three to four dependent groups (the early-exit test first, then the pinned batch, then words it
-    // sinks next to their use), each a scalar-cache miss of its own; with the lines already on their way those groups hit.
-    // (interleaved A/B: backward 8.72 -> 8.52 us.  Lines: this net's NetPtrs and NetGrad entries — first and last word,
-    //  an entry may straddle two lines — and the four lines from `log_std` to the end of the block, n_chunk / n_rt included.)
+  const int h_S = (int)(q_dims & 255u), h_A = (int)((q_dims >> 8) & 63u), h_pol = (int)((q_dims >> 14) & 1u);
+  const int h_ld = (int)(q_ldB & 1023u), h_rows = (int)(q_ldB >> 10);
+  const int h_MB = (int)(q_mbc & 0xFFFFu), n_chunk = (int)(q_mbc >> 16);
+  const int n_rt = (int)(q_rts & 1023u), h_spb = (int)(q_rts >> 10);
+  // Touch every 64-byte line of `p` this block will read, NOW and without waiting (one-slice instantiations only): the
+  // fetch in PIN_REST() below then finds the lines on their way — hipcc splits it into three to four dependent groups,
+  // each a scalar-cache miss of its own otherwise (interleaved A/B with the deferred fetch: backward 8.53 -> 8.29 us).
+  // hipcc does not see that an asm's scalar loads complete late, so the destination registers stay allocated — as
+  // operands of the waiting asm in PIN_REST() — until that wait, and the instantiations that do this must not spill
+  // SGPRs (a spilled destination's register is handed to a live value at once: the late write then corrupts it — a memory
+  // fault at 600 rows when the MULTI instantiations still did it); __graft_entry__.build() fails the build otherwise.
+  unsigned kpf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (!MULTI) {
     const unsigned long long ka = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-    const unsigned o_net = (unsigned)offsetof(StepParams, net) + (unsigned)sizeof(NetPtrs) * (unsigned)(x & 3);
-    const unsigned o_go = (unsigned)offsetof(StepParams, go) + (unsigned)sizeof(NetGrad) * (unsigned)(x & 3);
-    const unsigned o_t0 = (unsigned)offsetof(StepParams, log_std) & ~63u;
-    static_assert(sizeof(StepParams) + 8 - (offsetof(StepParams, log_std) & ~(size_t)63) <= 256, "kernel-argument tail: more than 4 lines");
+    constexpr unsigned KA_P = 56;       // `p` follows five pointers and four words in the argument block
+    const unsigned o_net = KA_P + (unsigned)offsetof(StepParams, net) + (unsigned)sizeof(NetPtrs) * (unsigned)(x & 3);
+    const unsigned o_go = KA_P + (unsigned)offsetof(StepParams, go) + (unsigned)sizeof(NetGrad) * (unsigned)(x & 3);
+    const unsigned o_t0 = (KA_P + (unsigned)offsetof(StepParams, log_std)) & ~63u;
+    static_assert(KA_P + sizeof(StepParams) - ((KA_P + offsetof(StepParams, log_std)) & ~(size_t)63) <= 256, "kernel-argument tail: more than 4 lines");
     unsigned d0, d1, d2, d3, d4, d5, d6, d7;
     asm volatile(
         "s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\t"
@@ -1072,12 +1130,12 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   // other six XCDs' queues (the first ceil(n_don / 6) grid rows; host: launch_bwd) — long blocks first: at the ends of
   // those queues they started at 22 us and finished at 36; their old slots return at once.
   const int n_a = 32 * n_chunk;
-  const int bsl2 = MULTI ? ((p.spb_l2 >> 2) & 3) : 0;     // (b) blocks: log2 of the column slices per block
+  const int bsl2 = MULTI ? ((h_spb >> 2) & 3) : 0;     // (b) blocks: log2 of the column slices per block
   const int n_b = (4 >> bsl2) * n_rt;
   int net = x & 3;
   int local_ = (bid >> 3) * 2 + (x >> 2);
   if (MULTI) {
-    const int n_don = p.spb_l2 >> 8;
+    const int n_don = h_spb >> 8;
     const int n_e = (n_don + 5) / 6;
     const int q = bid >> 3;
     if (q < n_e) {
@@ -1092,35 +1150,36 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int B = p.rows;
-  const int MB = p.sc.max_batch;
+  const int B = h_rows;
+  const int MB = h_MB;
+  const ArenaOff ao = arena_off(net, h_S, h_A, h_pol == IQLHIP_POLICY_GAUSSIAN);
 
   const NetPtrs np = p.net[net];
   const NetGrad go = p.go[net];
-  const int D = np.d;
+  const int D = ao.d;
   const int Dp = (D + 15) & ~15;      // 16 or 32
   const int DYLD = Dp + 4;            // dY row stride in LDS: 16-B aligned rows (float4 reads of a row's dims)
-  const float* w2 = np.w2;
+  const float* w2 = q_params + ao.w2;
   // (bf16 path: H0 / H1 are stored as bf16 — the same element offsets, half the bytes; the pointers below then carry
   //  the bf16 arrays' addresses and are only ever dereferenced through ld4 / ld2)
-  const float* H1g = BF16 ? (const float*)((const __bf16*)p.sc.h1 + net * MB * HID) : p.sc.h1 + net * MB * HID;
-  const float* H0g = BF16 ? (const float*)((const __bf16*)p.sc.h0 + net * MB * HID) : p.sc.h0 + net * MB * HID;
-  // dropout: the saved activations are post-dropout, so (h > 0) already encodes relu AND keep; the chain
-  // rule only adds the 1/(1-p) multiplier
-  const float dscale = (net == IQLHIP_NET_PI && p.drop_bits != nullptr) ? p.drop_scale : 1.f;
-  {
-    const float* xb_ = p.xb; const float* hd_ = p.sc.heads; float* sa_ = p.sc.slab_a; float* sb_ = p.sc.slab_b;
-    const int ld_ = p.ld, S_ = p.S, A_ = p.A, pol_ = p.policy, k0_ = np.k0;
-    const long long sbo_ = p.sc.slab_b_off[net], npar_ = p.n_params;
-    PIN_P(np.w1); PIN_P(np.w2); PIN_P(H1g); PIN_P(H0g); PIN_P(xb_); PIN_P(hd_); PIN_P(sa_); PIN_P(sb_);
-    PIN_S(D); PIN_S(B); PIN_S(MB); PIN_S(ld_); PIN_S(S_); PIN_S(A_); PIN_S(pol_); PIN_S(k0_);
-    PIN_S(sbo_); PIN_S(npar_); PIN_S(go.w1); PIN_S(go.b1); PIN_S(go.w2); PIN_S(go.b2); PIN_S(go.log_std);
-    PIN_S(p.inv_batch); PIN_S(p.hy.iql_tau); PIN_S(p.hy.beta); PIN_S(p.hy.discount); PIN_S(p.hy.exp_adv_max);
-    PIN_S(n_chunk); PIN_S(n_rt);
-  }
-  // the prefetch loads have landed by now (the pinned batch above was waited for with lgkmcnt(0), which covers every
-  // earlier scalar load): this wait is free, and its operands end the prefetch registers' live range HERE
-  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(kpf[0]), "s"(kpf[1]), "s"(kpf[2]), "s"(kpf[3]), "s"(kpf[4]), "s"(kpf[5]), "s"(kpf[6]), "s"(kpf[7]));
+  const float* H1g = BF16 ? (const float*)((const __bf16*)q_h1 + net * MB * HID) : q_h1 + net * MB * HID;
+  const float* H0g = BF16 ? (const float*)((const __bf16*)q_h0 + net * MB * HID) : q_h0 + net * MB * HID;
+  // Everything the block still needs from the by-value StepParams is fetched by PIN_REST(), which each branch invokes
+  // right BEHIND the issue of its first global loads: those depend on preloaded arguments only, so the ~500-cycle fetch
+  // of the argument block now runs under their latency instead of in front of them (one batch of scalar loads behind
+  // one wait; in the one-slice instantiations the lines were touched at the top and the prefetch registers' live range
+  // ends at the wait below, which is free by then).
+#define PIN_REST()                                                                                                          \
+  do {                                                                                                                      \
+    float* sa_ = p.sc.slab_a; float* sb_ = p.sc.slab_b;                                                                     \
+    const long long sbo_ = p.sc.slab_b_off[net], npar_ = p.n_params;                                                        \
+    PIN_P(np.w1); PIN_P(sa_); PIN_P(sb_);                                                                                   \
+    PIN_S(sbo_); PIN_S(npar_); PIN_S(go.w1); PIN_S(go.b1); PIN_S(go.w2); PIN_S(go.b2); PIN_S(go.log_std);                   \
+    PIN_S(p.inv_batch); PIN_S(p.hy.iql_tau); PIN_S(p.hy.beta); PIN_S(p.hy.discount); PIN_S(p.hy.exp_adv_max);               \
+    if constexpr (!MULTI)                                                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(kpf[0]), "s"(kpf[1]), "s"(kpf[2]), "s"(kpf[3]), "s"(kpf[4]), "s"(kpf[5]),   \
+                   "s"(kpf[6]), "s"(kpf[7]));                                                                               \
+  } while (0)
   if (local_ >= n_a + n_b) return;
   // MULTI: the (b) blocks walk 2 / 4 slices and run 2-3x as long as a dW1 tile — they take the FIRST block indices so
   // that the launch ends on short blocks (longest first); one-slice grids keep the dW1 tiles first
@@ -1153,28 +1212,27 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     const bool do_dw2 = (D == 1) ? (it == 0) : (it == 1 || it == 3);
     const int tb_own = (it == 3) ? 1 : 0;            // D > 1: which of a lane's two j columns this block's dW2 covers
     const bool extras = do_db1 || do_dw2;
-    float* slab = p.sc.slab_a + (long long)c * p.n_params;
 
     // ---- loads, in the order they are needed (vmcnt retires in issue order): the per-row loss
     // inputs first, then the 96 KiB of activation tiles, which stream in under the dY arithmetic.
     const int prow = cbase + tid;
     RowIn in;
-    const float lsr = pi_ls_issue(p);
+    const float lsr = pi_ls_issue_hot(q_params + ao.log_std, q_xb, h_pol, h_A);
     const bool is_pi = (net == IQLHIP_NET_PI);
-    row_issue(p, BROW(prow), in);           // scalar partials, r, d (the policy needs h[1..3] for w)
+    row_issue_hot(q_heads, q_xb, h_ld, h_S, h_A, BROW(prow), in);           // scalar partials, r, d (the policy needs h[1..3] for w)
     // Policy: its per-(row, dim) inputs are loaded as (row, dim) work items — thread (r8 = tid >> 3, sub = tid & 7)
     // takes rows r8 + 32c, c = 0..7, and action dim sub (+ 8e) — so that one load instruction touches 6-8 cache
     // lines.  With thread = row every such load touched 48-64 lines; the 16 of them held the load queue for 8.5 k
     // cycles and made the policy's (a) blocks (10-13 us) the long pole of the whole kernel (others: 6-9 us).
     const int r8 = tid >> 3, sub = tid & 7;
-    const f32x4* hpb = (const f32x4*)(p.sc.heads + MB * HEAD_LD);
-    const float* hpf = p.sc.heads + MB * HEAD_LD;
-    const float* xbp = p.xb;
+    const f32x4* hpb = (const f32x4*)(q_heads + MB * HEAD_LD);
+    const float* hpf = q_heads + MB * HEAD_LD;
+    const float* xbp = q_xb;
     f32x4 php[8];
     float pac[8];
     if (is_pi) {
-      const unsigned dd0 = (unsigned)min(sub, p.A - 1);
-      const unsigned uA = (unsigned)p.A, uld = (unsigned)p.ld, uS = (unsigned)p.S;
+      const unsigned dd0 = (unsigned)min(sub, h_A - 1);
+      const unsigned uA = (unsigned)h_A, uld = (unsigned)h_ld, uS = (unsigned)h_S;
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
         const unsigned rowc = (unsigned)BROW(cbase + r8 + 32 * cc);
@@ -1201,6 +1259,11 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       hh[ks] = ld2<BF16>(H1g, row * (unsigned)HID + (unsigned)(j0 + 2 * l15));
       bb[ks] = ld4<BF16>(H0g, row * (unsigned)HID + (unsigned)(i0 + 4 * l15));
     }
+    PIN_REST();
+    float* slab = p.sc.slab_a + (long long)c * p.n_params;
+    // dropout: the saved activations are post-dropout, so (h > 0) already encodes relu AND keep; the chain
+    // rule only adds the 1/(1-p) multiplier
+    const float dscale = (net == IQLHIP_NET_PI && p.drop_bits != nullptr) ? p.drop_scale : 1.f;
     STAMP(p, 10);
     // ---- dY for the 256 rows of the chunk (thread = row)
     {
@@ -1211,7 +1274,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         if (e < Dp * 32) W2s[e] = (e < D * 32) ? w2pre[q] : 0.f;
       }
       float lossA = 0.f, lossB = 0.f;
-      const PiConst pc = pi_consts(p, net, lsr);
+      const PiConst pc = pi_consts_hot(p, h_pol, net, lsr);
       if (!is_pi) {
         float* dyrow = dYs + tid * DYA;
         for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
@@ -1231,9 +1294,9 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
         // phase 2 (thread = (row, dim)): mean, log-prob term, dL/dpre and dL/dlog_std of every (row, dim) — eight
         // rows of one dim per thread and group of 8 dims, as straight-line select code (pi_items8): written with
         // per-item branches this phase was ~110 LDS / branch round trips (3.3 k cycles, the policy blocks' long pole)
-        const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
+        const bool gauss = (h_pol == IQLHIP_POLICY_GAUSSIAN);
         const bool want_dls = designated && gauss;
-        const int A = p.A;
+        const int A = h_A;
         const float invB = p.inv_batch;
         float wv[8];
 #pragma unroll
@@ -1257,7 +1320,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
               for (int cc = 0; cc < 8; ++cc) {
                 const unsigned rowc = (unsigned)BROW(cbase + r8 + 32 * cc);
                 hv[cc] = *(const f32x4*)(hpf + 4u * (rowc * (unsigned)A + (unsigned)ddc));
-                acv[cc] = xbp[rowc * (unsigned)p.ld + (unsigned)(p.S + ddc)];
+                acv[cc] = xbp[rowc * (unsigned)h_ld + (unsigned)(h_S + ddc)];
               }
               pi_items8(hv, acv, wv, dd < A, gauss, ivar, ls, invB, dyv, dlv, lossA);
             }
@@ -1290,7 +1353,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       // tile-reduction buffer is idle until after the MFMA phase; only wave 0's part of it is touched here).  A
       // dim per wave and iteration, each with its own load and store, took ~1.4 k cycles per dim: 9.7 k at D = 28
       // (for D <= 8 that loop, at most two dims per wave, is the cheaper one and stays).
-      const bool gls = (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN);
+      const bool gls = (net == IQLHIP_NET_PI && h_pol == IQLHIP_POLICY_GAUSSIAN);
       const int dd = tid & 31, rg = tid >> 5;
       float s = 0.f, sl = 0.f;
       if (dd < D) {
@@ -1330,7 +1393,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
       // the policy with D <= 8: thread (dim tid & 7, row group tid >> 3) sums 8 rows, the 32 partial sums per dim meet in LDS and are
       // added in row-group order by one thread per dim (a dim per wave and pass, with a 6-level shuffle tree per dim,
       // took 2.9 k cycles on the one block that does this — the last block of the whole kernel)
-      const bool gls = (net == IQLHIP_NET_PI && p.policy == IQLHIP_POLICY_GAUSSIAN);
+      const bool gls = (net == IQLHIP_NET_PI && h_pol == IQLHIP_POLICY_GAUSSIAN);
       const int dd = tid & 7, rg = tid >> 3;
       // (both stages are balanced trees: these sums cancel heavily — db2 of a Q net is sum_r (q - y) / B — and a
       //  sequential 256-term sum lost a digit against the reference: 2.1e-5 instead of 2.6e-6 on one fixture)
@@ -1554,8 +1617,8 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     const int rt = lb >> (2 - bsl2);
     int i0 = ((lb & ((4 >> bsl2) - 1)) << bsl2) * 64;      // first (or only) column slice of this block
     const int row0 = rt * RT_ROWS;
-    const int k0 = np.k0;
-    const int ld = p.ld;
+    const int k0 = ao.k0;
+    const int ld = h_ld;
     const int xoff = 0;                   // trainable nets read s or [s|a]: both start at column 0
     const float* w1 = np.w1;
 
@@ -1569,14 +1632,14 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // ---- issue every global load of the block, first-needed first (vmcnt retires in issue order)
     RowIn in;
     const int prow = BROW(row0 + (tid & 31));
-    const float lsr = pi_ls_issue(p);
+    const float lsr = pi_ls_issue_hot(q_params + ao.log_std, q_xb, h_pol, h_A);
     // the scalar nets' per-row loss inputs are consumed by the first 32 threads only: wave 0 alone loads them
     // (these loads head the in-order queue — issued by all four waves they delayed every load behind them);
     // the policy's own inputs follow below
 #pragma unroll
     for (int i = 0; i < 6; ++i) in.h[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     in.r = 0.f; in.d = 0.f;
-    if (wave == 0 && net != IQLHIP_NET_PI) row_issue(p, prow, in);
+    if (wave == 0 && net != IQLHIP_NET_PI) row_issue_hot(q_heads, q_xb, h_ld, h_S, h_A, prow, in);
     // policy: the loss arithmetic of the 32 rows is spread over all 256 threads — thread (row tid>>3,
     // dims (tid&7) + 8c) — instead of 32 threads walking all dims while 224 wait at the barrier
     const int prl = tid >> 3, psub = tid & 7;
@@ -1584,17 +1647,17 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     f32x4 ph[3], php[4];
     float pac[4];
     if (net == IQLHIP_NET_PI) {
-      const float* hsb = p.sc.heads;
+      const float* hsb = q_heads;
       const unsigned oh = (unsigned)prow8 * (unsigned)HEAD_LD;
       ph[0] = *(const f32x4*)(hsb + (oh + 4u)); ph[1] = *(const f32x4*)(hsb + (oh + 8u)); ph[2] = *(const f32x4*)(hsb + (oh + 12u));
-      const float* arow = p.xb + (unsigned)(prow8 * p.ld + p.S);
-      const f32x4* hp = (const f32x4*)(p.sc.heads + MB * HEAD_LD + (unsigned)(prow8 * p.A * NSPLIT));
+      const float* arow = q_xb + (unsigned)(prow8 * h_ld + h_S);
+      const f32x4* hp = (const f32x4*)(q_heads + MB * HEAD_LD + (unsigned)(prow8 * h_A * NSPLIT));
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         php[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         pac[c] = 0.f;
-        if (c == 0 || 8 * c < p.A) {               // block-uniform: dims >= 8 only for wide action spaces
-          const int dd = min(psub + 8 * c, p.A - 1);
+        if (c == 0 || 8 * c < h_A) {               // block-uniform: dims >= 8 only for wide action spaces
+          const int dd = min(psub + 8 * c, h_A - 1);
           php[c] = hp[dd];
           pac[c] = arow[dd];
         }
@@ -1635,22 +1698,24 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     }
     const int n_x = RT_ROWS * ld / 4;
     const int x_last = B * ld / 4 - 1;
+    PIN_REST();
+    const float dscale = (net == IQLHIP_NET_PI && p.drop_bits != nullptr) ? p.drop_scale : 1.f;
 
-    const PiConst pc = pi_consts(p, net, lsr);
+    const PiConst pc = pi_consts_hot(p, h_pol, net, lsr);
     if (net == IQLHIP_NET_PI) {
       const float tq = fminf(sum4(ph[1]), sum4(ph[2]));
       const float u = tq - sum4(ph[0]);
       const float w = fminf(expf(p.hy.beta * u), p.hy.exp_adv_max);
       const bool rvalid = (row0 + prl) < B;
-      const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
+      const bool gauss = (h_pol == IQLHIP_POLICY_GAUSSIAN);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int dd = psub + 8 * c;
         if (dd < Dp) {
           float dy = 0.f;
-          const int ddc = min(dd, p.A - 1);
+          const int ddc = min(dd, h_A - 1);
           const float ivar = __shfl(pc.ivar, ddc);        // lane ddc holds dim ddc's constants; whole wave active
-          if (rvalid && dd < p.A) {
+          if (rvalid && dd < h_A) {
             const float mu = tanh_via_exp(sum4(php[c]));
             const float diff = pac[c] - mu;
             const float dmu = gauss ? (-(w * diff) * ivar) * p.inv_batch : (-2.f * w * diff) * p.inv_batch;
@@ -1785,7 +1850,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
           hm[rtl][reg] = ld4<true>(H0g, row * (unsigned)HID + (unsigned)(64 * wave + 4 * l15));
         }
       f32x4 xr[XR_MAX_F4];
-      xr_load(xr, p.xb, row0 * ld / 4, n_x, x_last);
+      xr_load(xr, q_xb, row0 * ld / 4, n_x, x_last);
       bf16x8 Ad[2][8];
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
@@ -1875,7 +1940,7 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(StepParams p, int n_chunk,
     // the 32 packed rows, needed last (dW0): issued only now — the H1 / W2 registers are free again, the loads
     // queue behind the W1 fragments (so waiting for those does not wait for these) and the MFMA phase hides them
     f32x4 xr[XR_MAX_F4];
-    xr_load(xr, p.xb, row0 * ld / 4, n_x, x_last);
+    xr_load(xr, q_xb, row0 * ld / 4, n_x, x_last);
 
     // ======== per column slice (one pass unless MULTI): dH0 slice, dW0 / db0 slice.  The next slice's W1 fragments are
     // requested into the registers this slice's MFMAs have just consumed, its H0 mask under the MFMA phase.
