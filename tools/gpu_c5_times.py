@@ -13,7 +13,7 @@ import synth
 from hip_helpers import to_torch_batch
 
 S, A = 39, 28
-for B in (256, 1024):
+for B in (256, 1024, 8192):
     qf, vf, actor = iql.TwinQ(S, A).cuda(), iql.ValueFunction(S).cuda(), iql.GaussianPolicy(S, A, 1.0).cuda()
     tr = iql.ImplicitQLearning(1.0, actor, torch.optim.Adam(actor.parameters(), lr=3e-4), qf,
                                torch.optim.Adam(qf.parameters(), lr=3e-4), vf,
