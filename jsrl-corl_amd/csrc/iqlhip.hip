@@ -134,7 +134,7 @@ struct iqlhip_ctx {
   __bf16* wsh = nullptr;              // bf16 path: shadow of the parameter arena [n_params] (W1 is read from it) ...
   __bf16* tsh = nullptr;              // ... and of the target arena [n_target]; written by the update kernel, refreshed
                                       // from the fp32 masters at the start of every library call
-  float* loss_ring = nullptr;         // [ring_cap][4]
+  float* loss_ring = nullptr;         // [ring_cap][4], host-mapped pinned
   int ring_cap = 0;
   iqlhip_step_scalars* sched_cur = nullptr;   // [GRAPH_STEPS] device: per-step scalars of the chunk in flight
   iqlhip_step_scalars* sched_call = nullptr;  // [k_max] device copy of the scalar table of the call in flight
@@ -290,7 +290,10 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   HIPCHK(dalloc(&c->flat_tmp, (size_t)c->L.n_params + 4));
   c->k_max = 1024;
   c->ring_cap = c->k_max;
-  HIPCHK(dalloc(&c->loss_ring, (size_t)c->ring_cap * 4));
+  // the loss ring lives in host-mapped pinned memory: each step's update kernel posts its 3 words there, and the
+  // end of a train_steps call is ONE stream synchronisation queued right behind the work — no device-to-host copy
+  HIPCHK(hipHostMalloc((void**)&c->loss_ring, (size_t)c->ring_cap * 4 * sizeof(float), hipHostMallocDefault));
+  memset(c->loss_ring, 0, (size_t)c->ring_cap * 4 * sizeof(float));
   HIPCHK(hipMalloc((void**)&c->sched_cur, (size_t)GRAPH_STEPS * sizeof(iqlhip_step_scalars)));
   HIPCHK(hipMalloc((void**)&c->sched_call, (size_t)c->k_max * sizeof(iqlhip_step_scalars)));
   for (int i = 0; i < 4; ++i) {
@@ -402,13 +405,14 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
-                  c->flat_tmp, c->loss_ring, c->sched_call, c->sched_cur, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act,
+                  c->flat_tmp, c->sched_call, c->sched_cur, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act,
                   c->heads_act, c->drop_bits, c->xstatus, c->xflat, c->wsh, c->tsh};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < 4; ++i) {
     if (c->sched_pin[i]) (void)hipHostFree(c->sched_pin[i]);
   }
   if (c->sched_ack) (void)hipHostFree(c->sched_ack);
+  if (c->loss_ring) (void)hipHostFree(c->loss_ring);
   if (c->xstatus_host) (void)hipHostFree(c->xstatus_host);
   if (c->setup_arrivals) (void)hipFree(c->setup_arrivals);
   if (c->losses_host) (void)hipHostFree(c->losses_host);
@@ -1281,9 +1285,8 @@ extern "C" int iqlhip_read_losses(iqlhip_ctx* c, float out[3], void* stream) {
 extern "C" int iqlhip_read_loss_ring(iqlhip_ctx* c, float* out, int32_t n_steps, void* stream) {
   if (!c || !out) return fail(IQLHIP_EINVAL, "NULL argument");
   if (n_steps < 1 || n_steps > c->ring_cap) return fail(IQLHIP_EINVAL, "n_steps outside [1,%d]", c->ring_cap);
-  std::vector<float> h((size_t)n_steps * 4);
   const bool p2p = c->xch_mode == IQLHIP_XCH_P2P && c->world > 1;
-  HIPCHK(hipMemcpyAsync(h.data(), c->loss_ring, h.size() * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  const float* h = c->loss_ring;
   if (p2p) HIPCHK(hipMemcpyAsync(c->xstatus_host, c->xstatus, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   for (int k = 0; k < n_steps; ++k)
@@ -1304,7 +1307,8 @@ extern "C" int iqlhip_draw_indices(int64_t* idx_dev, int64_t n, int64_t size, ui
 
 // ---------------------------------------------------------------------------
 // The multi-step driver.  A call of n steps = ONE directly launched set-up kernel (header words, the call's scalar
-// table, step 0's rows unless the previous call left them staged) + replays of the fixed chunk graphs.  Everything a
+// table, step 0's rows unless the previous call left them staged) + its first 2 / 4 steps launched directly + replays
+// of the fixed chunk graphs.  Everything a
 // replay needs to differ in lives in device words that the set-up kernel writes once and each chunk's last update
 // kernel advances, so the chunks of a call follow each other with no host-side launch in between; the rows, scalars and
 // keep-bits of step k + 1 are staged by the idle eighth of step k's forward grid (IdleWork).
@@ -1486,7 +1490,26 @@ static GraphKey make_key(const iqlhip_ctx* c, const float* rows_dev, int64_t ld,
 }
 
 // Replay one chunk graph on `st`.  head: the call's first chunk — its set-up node gets this call's arguments first.
-static const bool g_no_head_graph = getenv("IQLHIP_NO_HEAD_GRAPH") != nullptr;     // diagnostic: direct set-up launch + plain chunk
+// How a call's first steps reach the GPU (IQLHIP_HEAD): "direct" (default) — the set-up kernel and the first 2 or 4
+// steps are launched kernel by kernel, so the GPU has work ~3 us after the call instead of after a graph launch
+// (~12 us), and the chunk launches that follow are hidden behind their execution; "graph" — round 3's first form, a head
+// chunk graph whose first node is the set-up kernel; "plain" — set-up kernel + plain chunks only (diagnostic).
+// profiles/r03_ab_experiments.txt #7: the driver's 20-step command 41.7 k -> 42.45 k steps/s with "direct".
+static const int g_head_mode = [] {
+  const char* e = getenv("IQLHIP_HEAD");
+  if (e && !strcmp(e, "graph")) return 1;
+  if (e && !strcmp(e, "plain")) return 2;
+  return 0;
+}();
+static const bool g_direct_head = g_head_mode == 0;
+static const bool g_no_head_graph = g_head_mode == 2;
+static const bool g_direct_all = getenv("IQLHIP_DIRECT_ALL") != nullptr;           // diagnostic: no graph replays at all
+static int n_chunks_for(int rem) {
+  int n = rem / GRAPH_STEPS;
+  rem %= GRAPH_STEPS;
+  for (int cs_ : {16, 4, 2, 1}) { n += rem / cs_; rem %= cs_; }
+  return n;
+}
 static int replay_chunk(iqlhip_ctx* c, hipStream_t st, const float* rows_dev, int64_t ld, int B, int n, float inv_batch,
                         const SetupArgs* head_args) {
   const int parity = (int)(c->xstep & 1ull);
@@ -1494,6 +1517,14 @@ static int replay_chunk(iqlhip_ctx* c, hipStream_t st, const float* rows_dev, in
   iqlhip_ctx::CachedGraph* cg = nullptr;
   int r = chunk_graph(c, make_key(c, rows_dev, ld, B, n, inv_batch, parity, head_args ? 1 : 0), &gexec, &cg);
   if (r) return r;
+  if (g_direct_all && !head_args) {      // experiment: the chunk's kernels launched one by one instead of the graph replay
+    r = enqueue_chunk(c, st, B, n, inv_batch, c->xch_mode, parity, cg->work);
+    if (r) return r;
+    cg->last = st;
+    c->drop_step += (unsigned long long)n;
+    if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += (unsigned long long)n;
+    return IQLHIP_OK;
+  }
   if (head_args) {
     hipKernelNodeParams np;
     memset(&np, 0, sizeof np);
@@ -1567,7 +1598,7 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
       h.w[HDR_DROP_STEP] = c->drop_step;
       h.w[HDR_DROP_SEED] = c->drop_seed;
       h.w[HDR_XSTEP] = c->xstep;
-      if (it.head && !g_no_head_graph) {
+      if (it.head) {
         SetupArgs a;
         fill_setup_args(c, a, h, slot, it.K, rows_dev, B, /*gather=*/true, cs);
         return replay_chunk(c, cs, rows_dev, ld, B, it.K, inv_batch, &a);
@@ -1577,8 +1608,8 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
       return replay_chunk(c, cs, rows_dev, ld, B, it.K, inv_batch, nullptr);
     };
     for (int pass = 0; pass < passes && !rc; ++pass)
-      for (const Item& it : items) { rc = rehearse(it); if (rc) break; }
-    for (int pass = 0; pass < passes && !rc; ++pass) rc = rehearse(Item{1, 1});
+      for (const Item& it : items) { if (it.head && g_head_mode != 1) continue; rc = rehearse(it); if (rc) break; }
+    for (int pass = 0; pass < passes && !rc && g_head_mode == 1; ++pass) rc = rehearse(Item{1, 1});
     // Sustained replays of the 64-step chunk (benign scalars, row 0, arenas restored below like the rest of the
     // rehearsal): the chip's clocks ramp up over the first milliseconds of a workload — a timed region that starts right
     // behind a capture-heavy (GPU-idle) prepare call measured its first 20 steps ~5 % slower than the following ones
@@ -1647,13 +1678,30 @@ extern "C" int iqlhip_train_steps(iqlhip_ctx* c, const float* rows_dev, int64_t 
   h.w[HDR_XSTEP] = c->xstep;
   refresh_shadows(c, st);
   if (g_trace) tr_t[1] = now_us();
-  // The call's first chunk is a HEAD chunk — 2 steps (1 for a one-step call) behind the set-up kernel, in one graph whose
-  // set-up node gets this call's arguments: one host-side launch until the GPU has work, and a short one (a graph
-  // launch costs ~10 us + 0.4 us per node on the host; the GPU starts when it returns).  The rest follows as plain
-  // chunks, the even sizes ascending (each launch is hidden behind the execution of what was launched before), the
-  // 64-step chunk as often as it fits, a one-step chunk — odd calls only — last.
+  // The call's HEAD — the set-up kernel and the first 2 or 4 steps (1 for a one-step call) — is launched kernel by
+  // kernel (g_head_mode; a graph launch costs ~10 us + 0.4 us per node on the host and the GPU starts when it returns,
+  // a kernel launch ~2.5 us).  The rest follows as chunk graphs, the even sizes ascending (each launch is hidden behind
+  // the execution of what was launched before), the 64-step chunk as often as it fits, a one-step chunk — odd calls
+  // only — last.
   int rem;
-  if (g_no_head_graph) {
+  if (g_direct_head) {
+    // 2 or 4 steps (even: a chunk's step 0 reads staging buffer 0), whichever leaves fewer chunk launches behind it —
+    // every launch boundary between chunks costs the GPU ~5 us (profiles/r03_train_steps_call_length.txt)
+    const int head_k = (K >= 4 && n_chunks_for(K - 4) < n_chunks_for(K - 2)) ? 4 : ((K >= 2) ? 2 : 1);
+    const int parity = (int)(c->xstep & 1ull);
+    hipGraphExec_t gexec = nullptr;
+    iqlhip_ctx::CachedGraph* cg = nullptr;
+    rc = chunk_graph(c, make_key(c, rows_dev, ld, B, head_k, inv_batch, parity, 0), &gexec, &cg);     // (for its idle-work records)
+    if (rc) return rc;
+    rc = launch_call_setup(c, st, h, slot, K, rows_dev, B, /*gather=*/!cont);
+    if (rc) return rc;
+    rc = enqueue_chunk(c, st, B, head_k, inv_batch, c->xch_mode, parity, cg->work);
+    if (rc) return rc;
+    cg->last = st;
+    c->drop_step += (unsigned long long)head_k;
+    if (c->xch_mode != IQLHIP_XCH_NONE) c->xstep += (unsigned long long)head_k;
+    rem = K - head_k;
+  } else if (g_no_head_graph) {
     rc = launch_call_setup(c, st, h, slot, K, rows_dev, B, /*gather=*/!cont);
     if (rc) return rc;
     rem = K;

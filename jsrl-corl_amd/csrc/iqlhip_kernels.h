@@ -2534,8 +2534,7 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
     if (u.done_flag) __hip_atomic_store(u.done_flag, u.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (u.loss_ring) {
       const long long slot = (long long)u.ring_slot + (u.ring_hdr ? (long long)u.ring_hdr[HDR_BASE] : 0ll);
-      float* rr = u.loss_ring + 4 * slot;
-      rr[0] = l[0]; rr[1] = l[1]; rr[2] = l[2]; rr[3] = 0.f;
+      *(float4*)(u.loss_ring + 4 * slot) = make_float4(l[0], l[1], l[2], 0.f);     // (host-mapped: one posted write)
     }
     if (u.adv_hdr) {      // the chunk is done: its successor finds its own per-launch values
       u.adv_hdr[HDR_POS] += (unsigned long long)u.adv_k * (unsigned long long)u.adv_rows;
