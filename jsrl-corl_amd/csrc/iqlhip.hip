@@ -677,7 +677,8 @@ static void launch_fwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t 
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   const int l2 = fwd_spb_l2(c, n_rt);
   p.spb_l2 = l2;
-  const int nb = 8 * n_rt * (NSPLIT >> l2);
+  // (full-width blocks: each XCD of a net's pair takes the row tiles of one parity — iql_fwd_kernel's block map)
+  const int nb = (l2 == 2) ? 8 * 2 * ((n_rt + 1) / 2) : 8 * n_rt * (NSPLIT >> l2);
   launch_fwd_grid(c, p, nb, st);
 }
 // Column slices per (b) block of the backward (log2): one while the whole grid — 4 nets x (32 dW1 tiles per 256-row
@@ -739,7 +740,13 @@ static void launch_dropmask(const iqlhip_ctx* c, unsigned long long seed, unsign
 }
 
 static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
-  const int nb = (int)((c->L.n_params / 4 + 255) / 256);
+  // grid: 8 x the 2 048-float windows of the longest net segment (iql_update_kernel's XCD-affine element map)
+  long long seg_max = 0;
+  for (int n = 0; n < 4; ++n) {
+    const long long end = (n < 3) ? c->L.net[n + 1].seg_begin : c->L.n_params;
+    seg_max = std::max(seg_max, end - c->L.net[n].seg_begin);
+  }
+  const int nb = 8 * (int)((seg_max + 2047) / 2048);
   const bool peer = u.n_peer > 0;
 #define UPD_LAUNCH(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P>), dim3(nb), dim3(256), 0, st, u)
   if (u.sched) { if (peer) UPD_LAUNCH(true, true); else UPD_LAUNCH(true, false); }

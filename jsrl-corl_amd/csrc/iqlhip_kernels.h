@@ -401,16 +401,42 @@ template <bool BF16, bool W0DMA, bool MULTI, bool ONE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void iql_fwd_kernel(StepParams p) {
   RT_ENTRY();
   const int bid = blockIdx.x;
-  const int inst = ONE ? p.only_inst : (bid & 7);
-  const int rest = ONE ? bid : (bid >> 3);
+  // XCD-affine block map (consecutive workgroups go round the 8 XCDs: XCD x = blockIdx & 7).  An L2 keeps what its own
+  // XCD wrote across a kernel boundary; a line another XCD wrote comes from memory (profiles/r01_l2_retention_microbench.txt:
+  // 11.7 vs 20.4 us for the same reads).  So the three kernels agree on who touches what: XCDs n and n + 4 belong to net
+  // n (V, Q1, Q2, pi) — the backward's blocks of net n run there, the update kernel's blocks there own the net's arena
+  // segment in 64-float stripes (even stripes on XCD n, odd ones on n + 4; W1 leads the segment with 4 stripes per row,
+  // so column slice ns of W1 is the stripes of parity ns & 1), and HERE the two forward instances that read net n's
+  // weights (or their target copy) share those two XCDs by column slice: slices of parity h on XCD n + 4 h.
+  //   XCD pair   0 / 4          1 / 5       2 / 6       3 / 7
+  //   instances  V(s), V(s')    Q1, Qt1     Q2, Qt2     pi, idle            (which = bit 0 of the block's index on its XCD)
+  // One-slice grids: W1 fragments come from the L2 the update kernel wrote them into, and the H0 columns this block
+  // saves are the ones the backward's dW1 tiles of the same parity read on this XCD.  Blocks that walk 2 slices take the
+  // pair {2 h, 2 h + 1}; blocks that walk all 4 take the row tiles of parity h.
+  const int fx = bid & 7, fh = fx >> 2, fr = bid >> 3;
+  constexpr unsigned FWD_PAIR_A = 0x6541u, FWD_PAIR_B = 0x7320u;      // nibble (x & 3): V(s) Q1 Q2 pi | V(s') Qt1 Qt2 idle
+  const int inst = ONE ? p.only_inst : (int)((((fr & 1) ? FWD_PAIR_B : FWD_PAIR_A) >> (4 * (fx & 3))) & 7u);
   if (inst >= 7) {     // the idle eighth of the grid: the chunk's bookkeeping for the NEXT step (graph chunks), else exits
-    if (p.g_work) idle_block_work(p.g_work, rest, (int)(gridDim.x >> 3));
+    if (p.g_work) idle_block_work(p.g_work, (fr >> 1) * 2 + fh, (int)(gridDim.x >> 3));
     return;
   }
   const int spb_l2 = MULTI ? (p.spb_l2 & 3) : 0;      // (MULTI = false: exactly the one-slice code, no loop)
   const int spb = 1 << spb_l2;
-  int ns = (rest & ((NSPLIT >> spb_l2) - 1)) << spb_l2;       // first (or only) column slice of this block
-  const int rt = rest >> (2 - spb_l2);
+  int ns, rt;
+  if (ONE) {           // blockIdx = row tile * NSPLIT + column slice
+    ns = bid & (NSPLIT - 1);
+    rt = bid >> 2;
+  } else if (spb_l2 == 0) {
+    ns = 2 * ((fr >> 1) & 1) + fh;
+    rt = fr >> 2;
+  } else if (spb_l2 == 1) {
+    ns = 2 * fh;
+    rt = fr >> 1;
+  } else {
+    ns = 0;
+    rt = 2 * (fr >> 1) + fh;
+    if (rt * RT_ROWS >= p.rows) return;      // (odd row-tile counts: the grid is rounded up to pairs of row tiles)
+  }
   const int row0 = rt * RT_ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -2422,9 +2448,18 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
                "s"(U64((uintptr_t)u.slab_a)), "s"(U64((uintptr_t)u.slab_b)), "s"(U64((uintptr_t)u.flat_grads)),
                "s"(U64((uintptr_t)u.sched)));
 #undef U64
-  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e < u.L.n_params) {
-    const int net = net_of(u.L, e);
+  // XCD-affine element map: block (x = blockIdx & 7, q = blockIdx >> 3) — XCD x under the round-robin workgroup
+  // dispatch — owns net x & 3, and of that net's arena segment the 64-float stripes of parity x >> 2: window q of 2 048
+  // floats, 16 stripes of 16 threads.  The backward's blocks of net n run on XCDs n and n + 4 and a dW1 tile of column
+  // parity h is written on XCD n + 4 h (W1 sits at the start of the segment, 4 stripes per row): the gradient is read
+  // from the L2 it was written into; the forward instances of net n (and the target copies') sit on XCDs n and n + 4
+  // and find half of the weights in their L2, and the optimizer state never leaves its XCD's L2.
+  const int ux = (int)(blockIdx.x & 7u), uq = (int)(blockIdx.x >> 3);
+  const int net = ux & 3, uhalf = ux >> 2;
+  const long long seg_b = (net == 0) ? u.L.net[0].seg_begin : ((net == 1) ? u.L.net[1].seg_begin : ((net == 2) ? u.L.net[2].seg_begin : u.L.net[3].seg_begin));
+  const long long seg_e = (net == 0) ? u.L.net[0].seg_end : ((net == 1) ? u.L.net[1].seg_end : ((net == 2) ? u.L.net[2].seg_end : u.L.net[3].seg_end));
+  const long long e = seg_b + (long long)uq * 2048 + (long long)((((int)threadIdx.x >> 4) * 2 + uhalf) * 64 + ((int)threadIdx.x & 15) * 4);
+  if (e < seg_e) {
     // issue the state loads before the gradient sum so that all of them are in flight together
     f32x4 m = *(f32x4*)(u.m + e);
     f32x4 v = *(f32x4*)(u.v + e);

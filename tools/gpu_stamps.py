@@ -95,7 +95,10 @@ def xcd_spans(name, blocks, last):
 
 n_rt = (B + 31) // 32
 fsl2 = int(os.environ.get("IQLHIP_FWD_SPB_L2", 0 if 8 * n_rt * 4 <= 256 else (1 if 8 * n_rt * 2 <= 256 else 2)))
-fwd_blocks = np.arange(8 * n_rt * (4 >> fsl2))
+fwd_blocks = np.arange(8 * 2 * ((n_rt + 1) // 2) if fsl2 == 2 else 8 * n_rt * (4 >> fsl2))
+# iql_fwd_kernel's block map: XCD pair (x & 3) hosts two instances, bit 0 of the block's index on its XCD says which
+FWD_NAMES = ("V(s)", "Q1", "Q2", "PI", "V(s')", "Qt1", "Qt2", "idle")
+fwd_inst = np.where(((fwd_blocks >> 3) & 1) == 0, fwd_blocks & 3, 4 + (fwd_blocks & 3))
 report("fwd slice 0 (after the layer-0 barrier)", fwd_blocks, [(2, "(layer-0 barrier)"), (8, "H0 save (+ next slice's W2/b1 requests)"), (9, "layer-1 operand reads + MFMAs"), (10, "epilogue + H1 tile write"), (11, "barrier"),
                                                               (12, "H1 save + head partials"), (13, "barrier before the next slice")])
 report("fwd", fwd_blocks, [(1, "prefetch+gather"), (5, "L0: LDS operand reads"), (6, "L0: MFMAs"), (7, "L0: epilogue + H0 writes"), (2, "L0: barrier"), (3, "H0 save + layer1"), (4, "H1 save + head")])
@@ -127,13 +130,13 @@ if os.environ.get("PER_NET"):
         isn = net_of == n
         report(f"bwd (a) net {nm}", bw[(local < 32 * n_chunk) & isn], LAB_A)
         report(f"bwd (b) net {nm}", bw[(local >= 32 * n_chunk) & (local < per_net) & isn], LAB_B)
-    for i, nm in enumerate(("V(s')", "V(s)", "Qt1", "Qt2", "Q1", "Q2", "PI")):
-        report(f"fwd inst {nm}", fwd_blocks[(fwd_blocks & 7) == i], [(1, "prefetch+gather"), (2, "layer0"), (3, "H0 save + layer1"), (4, "H1 save + head")])
+    for i, nm in enumerate(FWD_NAMES[:7]):
+        report(f"fwd inst {nm}", fwd_blocks[fwd_inst == i], [(1, "prefetch+gather"), (2, "layer0"), (3, "H0 save + layer1"), (4, "H1 save + head")])
 report("bwd (a) dW1 tiles", a_blocks, [(10, "issue loads"), (11, "wait heads + dY"), (1, "LDS zero/barrier"), (2, "designated b2/log_std"), (3, "loads + 128 MFMA"),
                                         (4, "reduce + store (+extras)")])
 report("bwd (b) dH0/dW0", b_blocks, [(5, "W1 prefetch+gather+dY(32)"), (6, "dH1 tile"), (7, "128 MFMA + red write"),
                                       (8, "reduce+mask"), (12, "dW0: LDS reads + MFMA"), (13, "dW0: stage T + barrier"), (9, "dW0: copy out")])
-realtime_report("fwd  all", fwd_blocks[(fwd_blocks & 7) != 7])
+realtime_report("fwd  all", fwd_blocks[fwd_inst != 7])
 realtime_report("bwd  (a)", a_blocks)
 realtime_report("bwd  (b)", b_blocks)
 realtime_report("bwd  all", bw)
@@ -143,8 +146,8 @@ for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
     sel = (local < 32 * n_chunk) & (net_of == n)
     for itv in range(4):
         realtime_report(f"bwd (a) {nm} it=={itv}", bw[sel & ((local & 3) == itv)])
-for i, nm in enumerate(("V(s')", "V(s)", "Qt1", "Qt2", "Q1", "Q2", "PI")):
-    realtime_report(f"fwd inst {nm}", fwd_blocks[(fwd_blocks & 7) == i])
+for i, nm in enumerate(FWD_NAMES[:7]):
+    realtime_report(f"fwd inst {nm}", fwd_blocks[fwd_inst == i])
 # clock estimate: cycles per 100 MHz tick over the fwd kernel
 blk = st[fwd_blocks]
 blk = blk[blk[:, 0] > 0]
