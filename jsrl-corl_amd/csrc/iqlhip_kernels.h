@@ -401,16 +401,17 @@ template <bool BF16, bool W0DMA, bool MULTI, bool ONE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void iql_fwd_kernel(StepParams p) {
   RT_ENTRY();
   const int bid = blockIdx.x;
-  // XCD-affine block map (consecutive workgroups go round the 8 XCDs: XCD x = blockIdx & 7).  An L2 keeps what its own
-  // XCD wrote across a kernel boundary; a line another XCD wrote comes from memory (profiles/r01_l2_retention_microbench.txt:
-  // 11.7 vs 20.4 us for the same reads).  So the three kernels agree on who touches what: XCDs n and n + 4 belong to net
+  // XCD-affine block map (consecutive workgroups go round the 8 XCDs: XCD x = blockIdx & 7).  Across a kernel boundary an
+  // XCD reads back what it wrote ITSELF much faster than what another XCD wrote (profiles/r01_l2_retention_microbench.txt:
+  // 11.7 vs 20.4 us for the same reads; the L2's FETCH_SIZE counters are the same either way — r03_pmc_summary.json — so
+  // the difference is on the memory side of the L2).  So the three kernels agree on who touches what: XCDs n and n + 4 belong to net
   // n (V, Q1, Q2, pi) — the backward's blocks of net n run there, the update kernel's blocks there own the net's arena
   // segment in 64-float stripes (even stripes on XCD n, odd ones on n + 4; W1 leads the segment with 4 stripes per row,
   // so column slice ns of W1 is the stripes of parity ns & 1), and HERE the two forward instances that read net n's
   // weights (or their target copy) share those two XCDs by column slice: slices of parity h on XCD n + 4 h.
   //   XCD pair   0 / 4          1 / 5       2 / 6       3 / 7
   //   instances  V(s), V(s')    Q1, Qt1     Q2, Qt2     pi, idle            (which = bit 0 of the block's index on its XCD)
-  // One-slice grids: W1 fragments come from the L2 the update kernel wrote them into, and the H0 columns this block
+  // One-slice grids: a block's W1 fragments were written by the update kernel's blocks on this XCD, and the H0 columns it
   // saves are the ones the backward's dW1 tiles of the same parity read on this XCD.  Blocks that walk 2 slices take the
   // pair {2 h, 2 h + 1}; blocks that walk all 4 take the row tiles of parity h.
   const int fx = bid & 7, fh = fx >> 2, fr = bid >> 3;
@@ -2452,8 +2453,8 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
   // dispatch — owns net x & 3, and of that net's arena segment the 64-float stripes of parity x >> 2: window q of 2 048
   // floats, 16 stripes of 16 threads.  The backward's blocks of net n run on XCDs n and n + 4 and a dW1 tile of column
   // parity h is written on XCD n + 4 h (W1 sits at the start of the segment, 4 stripes per row): the gradient is read
-  // from the L2 it was written into; the forward instances of net n (and the target copies') sit on XCDs n and n + 4
-  // and find half of the weights in their L2, and the optimizer state never leaves its XCD's L2.
+  // on the XCD that wrote it; the forward instances of net n (and the target copies') sit on XCDs n and n + 4 and read
+  // the stripes their own XCD wrote, and the optimizer state is only ever touched by one XCD.
   const int ux = (int)(blockIdx.x & 7u), uq = (int)(blockIdx.x >> 3);
   const int net = ux & 3, uhalf = ux >> 2;
   const long long seg_b = (net == 0) ? u.L.net[0].seg_begin : ((net == 1) ? u.L.net[1].seg_begin : ((net == 2) ? u.L.net[2].seg_begin : u.L.net[3].seg_begin));
