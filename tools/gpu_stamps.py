@@ -28,7 +28,7 @@ tr = iql.ImplicitQLearning(1.0, actor, torch.optim.Adam(actor.parameters(), lr=3
 if os.environ.get("PRECISION"):
     tr.train_on_buffer(buf, B, seed=7)
     tr.set_precision(os.environ["PRECISION"])
-for it in range(50):
+for it in range(int(os.environ.get("ITERS", 50))):        # (ITERS=3000: the chip's clocks have ramped by then)
     tr.train_on_buffer(buf, B, seed=7)
 torch.cuda.synchronize()
 raw = tr.debug_read("stamps")
