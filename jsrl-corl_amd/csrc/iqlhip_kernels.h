@@ -406,13 +406,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   // 11.7 vs 20.4 us for the same reads; the L2's FETCH_SIZE counters are the same either way — r03_pmc_summary.json — so
   // the difference is on the memory side of the L2).  So the three kernels agree on who touches what: XCDs n and n + 4 belong to net
   // n (V, Q1, Q2, pi) — the backward's blocks of net n run there, the update kernel's blocks there own the net's arena
-  // segment in 64-float stripes (even stripes on XCD n, odd ones on n + 4; W1 leads the segment with 4 stripes per row,
-  // so column slice ns of W1 is the stripes of parity ns & 1), and HERE the two forward instances that read net n's
+  // segment in 64-float stripes (even stripes on XCD n, odd ones on n + 4; W1 [unit][k] leads the segment with 4 stripes
+  // per row, so the k-slice i of W1 — a dW1 tile's columns, a (b) block's slice — is the stripes of parity i & 1), and
+  // HERE the two forward instances that read net n's
   // weights (or their target copy) share those two XCDs by column slice: slices of parity h on XCD n + 4 h.
   //   XCD pair   0 / 4          1 / 5       2 / 6       3 / 7
   //   instances  V(s), V(s')    Q1, Qt1     Q2, Qt2     pi, idle            (which = bit 0 of the block's index on its XCD)
-  // One-slice grids: a block's W1 fragments were written by the update kernel's blocks on this XCD, and the H0 columns it
-  // saves are the ones the backward's dW1 tiles of the same parity read on this XCD.  Blocks that walk 2 slices take the
+  // One-slice grids: the H0 columns a block saves are the ones the backward's dW1 tiles and (b) slices of the same parity
+  // read on this XCD (its own W1 rows span all k: half of their stripes were written here, half on the partner XCD —
+  // for every block alike, whatever the map).  Blocks that walk 2 slices take the
   // pair {2 h, 2 h + 1}; blocks that walk all 4 take the row tiles of parity h.
   const int fx = bid & 7, fh = fx >> 2, fr = bid >> 3;
   constexpr unsigned FWD_PAIR_A = 0x6541u, FWD_PAIR_B = 0x7320u;      // nibble (x & 3): V(s) Q1 Q2 pi | V(s') Qt1 Qt2 idle
