@@ -198,3 +198,25 @@ def test_bench_two_ranks_on_one_gpu_pick_the_peer_exchange_and_say_why():
     cfg = d["config"]
     assert cfg["exchange"] == "p2p" and cfg["exchange_probe"]["p2p"]["replicas_equal"] is True
     assert "only in-library exchange" in cfg["exchange_why"]
+
+
+def test_head_modes_and_forward_layouts_agree(tmp_path):
+    """How a train_steps call starts (IQLHIP_HEAD = direct / graph / plain, IQLHIP_DIRECT_ALL) and how many slices a forward
+    or backward block walks are placement and launch choices only: losses of every step and the parameters after 98
+    steps are identical, bit for bit, across all of them (each variant in a fresh process: the switches are read when the
+    library is loaded)."""
+    variants = [{}, {"IQLHIP_HEAD": "graph"}, {"IQLHIP_HEAD": "plain"}, {"IQLHIP_DIRECT_ALL": "1"},
+                {"IQLHIP_FWD_SPB_L2": "2", "IQLHIP_BWD_SPB_L2": "2"}]
+    worker = os.path.join(ROOT, "tests", "head_mode_worker.py")
+    outs = []
+    for i, extra in enumerate(variants):
+        env = dict(os.environ)
+        env.update(extra)
+        path = os.path.join(tmp_path, f"v{i}.json")
+        r = subprocess.run([sys.executable, worker, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout.decode("utf-8", "replace")[-3000:]
+        outs.append(json.load(open(path)))
+    for i, o in enumerate(outs[1:], 1):
+        assert o["losses"] == outs[0]["losses"], variants[i]
+        assert o["params"] == outs[0]["params"], variants[i]
+    assert len(outs[0]["losses"]) == 98 and np.all(np.isfinite(np.array(outs[0]["losses"])))
