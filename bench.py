@@ -19,8 +19,8 @@ N > 1: BASELINE.json configs[3] (obs=17, act=6, 10M-row buffer replicated per GP
        Launched without torch.distributed.run (WORLD_SIZE unset), `--gpus N` spawns the N rank processes itself.
 
 The timed region never contains a graph capture or instantiation for ANY --steps/--warmup: the library composes a
-run from replays of two fixed chunk graphs (64 and 16 steps; captured, instantiated and rehearsed by prepare_train_steps before
-the warm-up) plus directly launched steps.
+run from its first 2 or 4 steps launched directly plus replays of fixed chunk graphs (64 / 16 / 4 / 2 / 1 steps; captured,
+instantiated and rehearsed by prepare_train_steps before the warm-up).
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) with `roofline` (the backward kernel, the step's
 dominant launch, against the fp32-MFMA peak) and, at N = 1, `cpu_baseline` (oracle/iql_torch_port.py — a PyTorch-CPU

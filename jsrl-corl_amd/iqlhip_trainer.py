@@ -686,8 +686,8 @@ class ImplicitQLearning:
         """n_steps consecutive `sample -> train` iterations without host round trips
         (the offline loop body, algorithms/offline/iql.py:631-635): indices are drawn on
         the device (uniform with replacement, Philox keyed by (seed, total_it)); the library
-        replays ONE captured 64-step hipGraph chunk as often as it fits and launches the
-        remaining steps directly, so the cost per step does not depend on n_steps; per-step
+        launches the call's first 2 or 4 steps directly and replays fixed chunk graphs of 64 /
+        16 / 4 / 2 / 1 steps for the rest (nothing is captured per value of n_steps); per-step
         Adam / cosine-LR scalars are precomputed on the host (the next call's while the GPU
         runs this one's).  Under data parallelism every rank draws its own rows (rank-offset
         stream) and the gradient exchange runs inside the same stream / graph.  Returns losses
