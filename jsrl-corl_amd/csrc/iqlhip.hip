@@ -1,6 +1,7 @@
 // iqlhip.hip — C ABI (include/iqlhip.h) of the MI355X IQL step.  Host side:
 // arena layout, scratch management, launches, hipGraph capture of K-step chunks.
 #include "iqlhip_kernels.h"
+#include "iqlhip_lb_kernels.h"
 
 #include <dlfcn.h>
 
@@ -157,6 +158,11 @@ struct iqlhip_ctx {
   int bwd_donate_pct = -1;            // diagnostic (IQLHIP_BWD_DONATE_PCT): share of the policy's dW1 tiles run on the other XCDs
   int bwd_spb_force = -1;             // the same for the backward's (b) blocks (IQLHIP_BWD_SPB_L2)
   int fwd_spb_force = -1;             // diagnostic (IQLHIP_FWD_SPB_L2): fixed slices-per-block exponent of the forward
+  // large-batch bf16 path (iqlhip_lb_kernels.h): bf16 precision and more than LB_MIN_ROWS rows per step
+  float* pi_t = nullptr;              // [max_batch][32] T | [max_batch][32] G | [max_batch] L: the policy's loss terms without w
+  int lb_enabled = 1;                 // diagnostic (IQLHIP_LB=0): keep the small-batch kernels at every batch size
+  int lb_nbb_force = -1, lb_cpb_force = -1, lb_nbi_force = -1;   // diagnostic (IQLHIP_LB_NBB / _CPB / _NBI)
+  size_t lds_bwd_lb = 0;
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
   hipStream_t cap_stream = nullptr;
   struct CachedGraph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long stamp; hipStream_t last;
@@ -286,6 +292,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   }
   HIPCHK(dalloc(&c->sc.slab_b, sb));
   HIPCHK(dalloc(&c->sc.loss_parts, 4 * 64));
+  HIPCHK(dalloc(&c->pi_t, (size_t)MB * 65));
   HIPCHK(dalloc(&c->sc.losses, 4));
   HIPCHK(dalloc(&c->flat_tmp, (size_t)c->L.n_params + 4));
   c->k_max = 1024;
@@ -332,6 +339,10 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   if (const char* ov = getenv("IQLHIP_BWD_DONATE_PCT")) c->bwd_donate_pct = std::max(0, std::min(100, atoi(ov)));   // diagnostic (tools/)
   if (const char* ov = getenv("IQLHIP_BWD_SPB_L2")) c->bwd_spb_force = std::max(0, std::min(2, atoi(ov)));   // diagnostic (tools/)
   if (const char* ov = getenv("IQLHIP_FWD_SPB_L2")) c->fwd_spb_force = std::max(0, std::min(2, atoi(ov)));   // diagnostic (tools/)
+  if (const char* ov = getenv("IQLHIP_LB")) c->lb_enabled = atoi(ov) != 0;                                     // diagnostic (tools/)
+  if (const char* ov = getenv("IQLHIP_LB_NBB")) c->lb_nbb_force = std::max(2, atoi(ov));
+  if (const char* ov = getenv("IQLHIP_LB_CPB")) c->lb_cpb_force = std::max(1, atoi(ov));
+  if (const char* ov = getenv("IQLHIP_LB_NBI")) c->lb_nbi_force = std::max(2, atoi(ov));
   c->lds_fwd = fwd_fixed + (size_t)HID * w0_lds_k * sizeof(float) + (w0_lds_k > W0_LDS_MAX_K ? 4096 : 0);
   // One block per CU while the grid fits the chip (co-resident blocks share a CU's L1 and fill rate and only slow
   // each other down); the exact size — two blocks per CU where it is <= 80 KB — once there are more blocks than CUs.
@@ -361,6 +372,17 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
                           (const void*)iql_bwd_kernel<false, false, true>,  (const void*)iql_bwd_kernel<false, true, true>,
                           (const void*)iql_bwd_kernel<true, false, true>,   (const void*)iql_bwd_kernel<true, true, true>};
     for (const void* f : bwd) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
+  }
+  {
+    // large-batch backward: (a) blocks [tile reduction | dY rows x dims | dY dims x rows | W2^T | w | column partials | extras],
+    // (b) blocks [dH1 tile | dH0^T | X^T | dY | dy] (iql_bwd_lb_kernel)
+    const size_t lb_a = (size_t)(4 * 32 * T64_LD) * 4 + (size_t)(CHUNK_ROWS * LB_DYLD + 32 * H0B_LD) * 2 +
+                        (size_t)(CHUNK_ROWS + CHUNK_ROWS * LB_HDLD + 2 * 32 * 32 + 16 * 64 + 64) * 4;
+    const size_t lb_b = (size_t)(32 * H0B_LD + 256 * LB_DYLD + 16 * 5 * LB_DYLD + 32 * LB_DYLD + 32 * H0B_LD) * 2 + 32 * 4 + 64;
+    const size_t lb_park = (size_t)4 * 64 * (size_t)(dims->state_dim + A) * 4;      // (b) blocks: the slab rows on their way out
+    c->lds_bwd_lb = std::max(std::max(lb_a, lb_b), lb_park);
+    const void* lbk[2] = {(const void*)iql_bwd_lb_kernel<3>, (const void*)iql_bwd_lb_kernel<5>};
+    for (const void* f : lbk) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd_lb));
   }
   return IQLHIP_OK;
 }
@@ -406,7 +428,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
                   c->flat_tmp, c->sched_call, c->sched_cur, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act,
-                  c->heads_act, c->drop_bits, c->xstatus, c->xflat, c->wsh, c->tsh};
+                  c->heads_act, c->drop_bits, c->xstatus, c->xflat, c->wsh, c->tsh, c->pi_t};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < 4; ++i) {
     if (c->sched_pin[i]) (void)hipHostFree(c->sched_pin[i]);
@@ -560,6 +582,38 @@ static NetPtrs net_ptrs(const iqlhip_net_layout& nl, const float* base) {
   return n;
 }
 
+// ---------------------------------------------------------------------------
+// Large-batch bf16 path (iqlhip_lb_kernels.h): which steps take it, and how their rows are spread over blocks.
+#define LB_MIN_ROWS 512
+static bool use_lb(const iqlhip_ctx* c, int rows) {
+  if (c->precision != 1 || !c->lb_enabled || rows <= LB_MIN_ROWS) return false;
+  if (c->fwd_spb_force >= 0 || c->bwd_spb_force >= 0) return false;      // (diagnostic layouts of the small-batch kernels)
+  return c->dims.state_dim + c->dims.action_dim + 1 <= 16 * 5;           // [dW0 | db0] tiles a (b) block keeps in registers
+}
+struct LbGeom { int n_rt, n_chunk, nbi, nbb, cpb, n_cg; };
+static LbGeom lb_geom(const iqlhip_ctx* c, int rows) {
+  LbGeom g;
+  g.n_rt = (rows + RT_ROWS - 1) / RT_ROWS;
+  g.n_chunk = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  const int even_rt = (g.n_rt + 1) & ~1;
+  // forward: 7 instances + the idle eighth share the chip: 32 blocks per instance, each walks ceil(n_rt / 32) row tiles
+  g.nbi = std::min(even_rt, c->lb_nbi_force > 0 ? (c->lb_nbi_force + 1) & ~1 : 32);
+  // backward: a net's blocks live on its two XCDs (64 CUs): (b) blocks of up to n_rt / nbb row tiles, (a) blocks of cpb chunks
+  g.nbb = std::min(even_rt, c->lb_nbb_force > 0 ? (c->lb_nbb_force + 1) & ~1 : 32);
+  g.cpb = c->lb_cpb_force > 0 ? std::min(c->lb_cpb_force, g.n_chunk) : std::max(1, std::min(8, g.n_chunk / 2));
+  g.n_cg = (g.n_chunk + g.cpb - 1) / g.cpb;
+  return g;
+}
+static LbArgs lb_args(const iqlhip_ctx* c, int rows) {
+  const LbGeom g = lb_geom(c, rows);
+  LbArgs a;
+  a.pi_t = c->pi_t;
+  a.pi_g = c->pi_t + (size_t)c->dims.max_batch * 32;
+  a.pi_l = c->pi_t + (size_t)c->dims.max_batch * 64;
+  a.n_rt = g.n_rt; a.n_chunk = g.n_chunk; a.nbi = g.nbi; a.nbb = g.nbb; a.cpb = g.cpb; a.n_cg = g.n_cg;
+  return a;
+}
+
 static StepParams make_step(const iqlhip_ctx* c, int rows, float inv_batch) {
   StepParams p;
   memset(&p, 0, sizeof p);
@@ -626,6 +680,12 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.ring_slot = 0;
   u.n_chunk = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
   u.n_rt = (rows + RT_ROWS - 1) / RT_ROWS;
+  u.n_loss = u.n_chunk;
+  if (use_lb(c, rows)) {      // the large-batch backward writes one slab per chunk group / per (b) block
+    const LbGeom gm = lb_geom(c, rows);
+    u.n_chunk = gm.n_cg;
+    u.n_rt = gm.nbb;
+  }
   u.batch_rows = rows;
   u.sched = nullptr;
   u.sched_idx = 0;
@@ -674,6 +734,15 @@ static int fwd_spb_l2(const iqlhip_ctx* c, int n_rt) {
 }
 static void launch_fwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t st) {
   StepParams p = p_in;
+  if (p.only_inst < 0 && use_lb(c, p.rows)) {
+    const LbArgs a = lb_args(c, p.rows);
+    const int kq = c->dims.state_dim + c->dims.action_dim;
+    const dim3 grid(8 * a.nbi);
+    if (kq <= 32) hipLaunchKernelGGL(iql_fwd_lb_kernel<1>, grid, dim3(256), 0, st, p, a);
+    else if (kq <= 64) hipLaunchKernelGGL(iql_fwd_lb_kernel<2>, grid, dim3(256), 0, st, p, a);
+    else hipLaunchKernelGGL(iql_fwd_lb_kernel<3>, grid, dim3(256), 0, st, p, a);
+    return;
+  }
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   const int l2 = fwd_spb_l2(c, n_rt);
   p.spb_l2 = l2;
@@ -691,6 +760,14 @@ static int bwd_spb_l2(const iqlhip_ctx* c, int n_chunk, int n_rt) {
 }
 static void launch_bwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t st) {
   StepParams p = p_in;
+  if (use_lb(c, p.rows)) {
+    const LbArgs a = lb_args(c, p.rows);
+    const int kq = c->dims.state_dim + c->dims.action_dim;
+    const dim3 grid(8 * ((32 * a.n_cg + a.nbb + 1) / 2));
+    if (kq + 1 <= 48) hipLaunchKernelGGL(iql_bwd_lb_kernel<3>, grid, dim3(256), c->lds_bwd_lb, st, p, a);
+    else hipLaunchKernelGGL(iql_bwd_lb_kernel<5>, grid, dim3(256), c->lds_bwd_lb, st, p, a);
+    return;
+  }
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
   const int n_chunk = (p.rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
   int l2 = bwd_spb_l2(c, n_chunk, n_rt);

@@ -2160,7 +2160,9 @@ struct UpdParams {
   float* losses_mirror;     // nullable: second copy of the three losses (host-mapped pinned words: iqlhip_online_step)
   float* loss_ring;         // nullable
   int ring_slot;
-  int n_chunk, n_rt;
+  int n_chunk, n_rt;        // chunk slabs (slab_a) and row-tile slabs (slab_b) the backward wrote
+  int n_loss;               // 256-row chunks of the batch = entries of loss_parts per loss (the large-batch backward writes
+                            // fewer slabs than chunks: iqlhip_lb_kernels.h)
   int batch_rows;
   const iqlhip_step_scalars* sched;  // when non-null the scalars of this launch are sched[sched_idx]
   int sched_idx;                     // (hipGraph replay: kernel arguments are frozen, the table is not)
@@ -2240,7 +2242,7 @@ __device__ __forceinline__ f32x4 slab_grad(const UpdParams& u, long long e, int 
 
 __device__ __forceinline__ void loss_words(const UpdParams& u, float out[4]) {
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < u.n_chunk; ++c)
+  for (int c = 0; c < u.n_loss; ++c)
 #pragma unroll
     for (int k = 0; k < 4; ++k) s[k] += u.loss_parts[k * 64 + c];
   out[0] = s[0];   // sum_r w u^2

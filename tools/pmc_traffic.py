@@ -32,6 +32,11 @@ for k, c in out.items():
     res[k] = {"launches": max(len(fs), len(ws)), "FETCH_SIZE_KiB_avg": f_avg, "WRITE_SIZE_KiB_avg": w_avg,
               "hbm_bytes_per_launch_corrected": (None if f_avg is None or w_avg is None else (2 * f_avg + w_avg) * 1024)}
     # SQ pass (per launch averages; SQ_* are summed over the chip's SIMDs/CUs as rocprofv3 reports them)
+    other = {n: sum(v) / len(v) for n, v in c.items() if n.startswith(("TCC_", "TCP_")) and v}
+    if other:
+        res[k]["cache_per_launch"] = other
+        if "TCC_HIT_sum" in other and "TCC_MISS_sum" in other and other["TCC_HIT_sum"] + other["TCC_MISS_sum"] > 0:
+            res[k]["l2_hit_rate"] = other["TCC_HIT_sum"] / (other["TCC_HIT_sum"] + other["TCC_MISS_sum"])
     sq = {n: sum(v) / len(v) for n, v in c.items() if n.startswith(("SQ_", "GRBM_")) and v}
     if sq:
         res[k]["sq_per_launch"] = sq
