@@ -160,6 +160,9 @@ struct iqlhip_ctx {
   int fwd_spb_force = -1;             // diagnostic (IQLHIP_FWD_SPB_L2): fixed slices-per-block exponent of the forward
   // large-batch bf16 path (iqlhip_lb_kernels.h): bf16 precision and more than LB_MIN_ROWS rows per step
   float* pi_t = nullptr;              // [max_batch][32] T | [max_batch][32] G | [max_batch] L: the policy's loss terms without w
+  __bf16* dh1g = nullptr;             // [4][max_batch][256] dH1 rows, [4][max_batch][256] dH0 rows, [max_batch][32] policy dY (allocated
+  float* slab_x = nullptr;            // with the bf16 shadows); [64][n_params] the row blocks' partial sums
+  __bf16* wimg = nullptr;             // bf16 path: operand images of W1 / W0, [6][IMG_STRIDE] (iqlhip_kernels.h)
   int lb_enabled = 1;                 // diagnostic (IQLHIP_LB=0): keep the small-batch kernels at every batch size
   int lb_nbb_force = -1, lb_cpb_force = -1, lb_nbi_force = -1;   // diagnostic (IQLHIP_LB_NBB / _CPB / _NBI)
   size_t lds_bwd_lb = 0;
@@ -374,15 +377,10 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
     for (const void* f : bwd) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd));
   }
   {
-    // large-batch backward: (a) blocks [tile reduction | dY rows x dims | dY dims x rows | W2^T | w | column partials | extras],
-    // (b) blocks [dH1 tile | dH0^T | X^T | dY | dy] (iql_bwd_lb_kernel)
-    const size_t lb_a = (size_t)(4 * 32 * T64_LD) * 4 + (size_t)(CHUNK_ROWS * LB_DYLD + 32 * H0B_LD) * 2 +
-                        (size_t)(CHUNK_ROWS + CHUNK_ROWS * LB_HDLD + 2 * 32 * 32 + 16 * 64 + 64) * 4;
-    const size_t lb_b = (size_t)(32 * H0B_LD + 256 * LB_DYLD + 16 * 5 * LB_DYLD + 32 * LB_DYLD + 32 * H0B_LD) * 2 + 32 * 4 + 64;
-    const size_t lb_park = (size_t)4 * 64 * (size_t)(dims->state_dim + A) * 4;      // (b) blocks: the slab rows on their way out
-    c->lds_bwd_lb = std::max(std::max(lb_a, lb_b), lb_park);
-    const void* lbk[2] = {(const void*)iql_bwd_lb_kernel<3>, (const void*)iql_bwd_lb_kernel<5>};
-    for (const void* f : lbk) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd_lb));
+    // large-batch backward, row blocks: [dH1 tile | H1 tile | dH0 tile | dY | dy] (iql_bwd_rows_kernel)
+    c->lds_bwd_lb = (size_t)(3 * 32 * H0B_LD + 32 * LB_DYLD) * 2 + 32 * 4 +
+                    (size_t)(2 * 16 * 260 + 2 * 32 * 32 + 4 * 256 + 16) * 4;      // (+ the block sums' partials)
+    HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd_lb));
   }
   return IQLHIP_OK;
 }
@@ -428,7 +426,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   void* bufs[] = {c->sc.h0, c->sc.h1, c->sc.heads, c->sc.slab_a, c->sc.slab_b, c->sc.loss_parts, c->sc.losses,
                   c->flat_tmp, c->sched_call, c->sched_cur, c->hdr, c->stamps, c->xb, c->xb2, c->xb_act,
-                  c->heads_act, c->drop_bits, c->xstatus, c->xflat, c->wsh, c->tsh, c->pi_t};
+                  c->heads_act, c->drop_bits, c->xstatus, c->xflat, c->wsh, c->tsh, c->pi_t, c->dh1g, c->slab_x, c->wimg};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int i = 0; i < 4; ++i) {
     if (c->sched_pin[i]) (void)hipHostFree(c->sched_pin[i]);
@@ -462,6 +460,14 @@ extern "C" int iqlhip_set_precision(iqlhip_ctx* c, int mode) {
     DevGuard guard(c->device);
     HIPCHK(hipMalloc((void**)&c->wsh, (size_t)up(c->L.n_params, 64) * sizeof(__bf16)));
     HIPCHK(hipMalloc((void**)&c->tsh, (size_t)up(c->L.n_target, 64) * sizeof(__bf16)));
+    // scratch of the large-batch backward (iqlhip_lb_kernels.h)
+    const size_t MB = (size_t)c->dims.max_batch;
+    HIPCHK(hipMalloc((void**)&c->dh1g, (8 * MB * HID + MB * 32 + MB * LB_XLD + 4 * 65536) * sizeof(__bf16)));
+    HIPCHK(hipMemset(c->dh1g, 0, (8 * MB * HID + MB * 32 + MB * LB_XLD + 4 * 65536) * sizeof(__bf16)));
+    HIPCHK(hipMalloc((void**)&c->wimg, (size_t)6 * IMG_STRIDE * sizeof(__bf16)));
+    HIPCHK(hipMemset(c->wimg, 0, (size_t)6 * IMG_STRIDE * sizeof(__bf16)));
+    HIPCHK(hipMalloc((void**)&c->slab_x, (size_t)64 * c->L.n_params * sizeof(float)));
+    HIPCHK(hipMemset(c->slab_x, 0, (size_t)64 * c->L.n_params * sizeof(float)));
   }
   c->precision = mode;
   return IQLHIP_OK;
@@ -599,8 +605,9 @@ static LbGeom lb_geom(const iqlhip_ctx* c, int rows) {
   // forward: 7 instances + the idle eighth share the chip: 32 blocks per instance, each walks ceil(n_rt / 32) row tiles
   g.nbi = std::min(even_rt, c->lb_nbi_force > 0 ? (c->lb_nbi_force + 1) & ~1 : 32);
   // backward: a net's blocks live on its two XCDs (64 CUs): (b) blocks of up to n_rt / nbb row tiles, (a) blocks of cpb chunks
-  g.nbb = std::min(even_rt, c->lb_nbb_force > 0 ? (c->lb_nbb_force + 1) & ~1 : 32);
-  g.cpb = c->lb_cpb_force > 0 ? std::min(c->lb_cpb_force, g.n_chunk) : std::max(1, std::min(8, g.n_chunk / 2));
+  g.nbb = std::min(std::min(even_rt, 64), c->lb_nbb_force > 0 ? (c->lb_nbb_force + 1) & ~1 : 32);
+  // GEMM blocks: 28 jobs per net and chunk group; about four chunk groups keep >= 400 blocks in flight
+  g.cpb = c->lb_cpb_force > 0 ? std::min(c->lb_cpb_force, g.n_chunk) : std::max(1, std::min(8, g.n_chunk / 4));
   g.n_cg = (g.n_chunk + g.cpb - 1) / g.cpb;
   return g;
 }
@@ -611,6 +618,15 @@ static LbArgs lb_args(const iqlhip_ctx* c, int rows) {
   a.pi_g = c->pi_t + (size_t)c->dims.max_batch * 32;
   a.pi_l = c->pi_t + (size_t)c->dims.max_batch * 64;
   a.n_rt = g.n_rt; a.n_chunk = g.n_chunk; a.nbi = g.nbi; a.nbb = g.nbb; a.cpb = g.cpb; a.n_cg = g.n_cg;
+  const size_t MB = (size_t)c->dims.max_batch;
+  a.dh1g = c->dh1g;
+  a.dh0g = c->dh1g + 4 * MB * HID;
+  a.dyg = c->dh1g + 8 * MB * HID;
+  a.xbf = a.dyg + MB * 32;
+  a.w1t = a.xbf + MB * LB_XLD;
+  a.slab_x = c->slab_x;
+  a.wimg = c->wimg;
+  for (int n = 0; n < 4; ++n) { a.go_w0[n] = c->L.net[n].w0; a.go_b0[n] = c->L.net[n].b0; }
   return a;
 }
 
@@ -681,10 +697,14 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.n_chunk = (rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
   u.n_rt = (rows + RT_ROWS - 1) / RT_ROWS;
   u.n_loss = u.n_chunk;
-  if (use_lb(c, rows)) {      // the large-batch backward writes one slab per chunk group / per (b) block
+  u.slab_x = nullptr;
+  u.n_x = 0;
+  if (use_lb(c, rows)) {      // the large-batch backward writes one slab per chunk group and one per row block
     const LbGeom gm = lb_geom(c, rows);
     u.n_chunk = gm.n_cg;
-    u.n_rt = gm.nbb;
+    u.slab_x = c->slab_x;
+    u.n_x = gm.nbb;
+    u.n_loss = gm.nbb;
   }
   u.batch_rows = rows;
   u.sched = nullptr;
@@ -694,6 +714,8 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
   u.done_flag = nullptr; u.done_val = 0;
   u.wsh = (c->precision == 1) ? c->wsh : nullptr;
   u.tsh = (c->precision == 1) ? c->tsh : nullptr;
+  u.wimg = (c->precision == 1 && use_lb(c, rows)) ? c->wimg : nullptr;      // (read by the large-batch forward only)
+  if (getenv("IQLHIP_LB_NOIMG")) u.wimg = nullptr;                          // timing experiment only: stale images
   u.n_peer = 0;
   u.peer_direct = 0;
   for (int r = 0; r < IQLHIP_MAX_WORLD; ++r) { u.peer_flat[r] = nullptr; u.peer_slab_b[r] = nullptr; u.peer_loss[r] = nullptr; }
@@ -763,9 +785,9 @@ static void launch_bwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t 
   if (use_lb(c, p.rows)) {
     const LbArgs a = lb_args(c, p.rows);
     const int kq = c->dims.state_dim + c->dims.action_dim;
-    const dim3 grid(8 * ((32 * a.n_cg + a.nbb + 1) / 2));
-    if (kq + 1 <= 48) hipLaunchKernelGGL(iql_bwd_lb_kernel<3>, grid, dim3(256), c->lds_bwd_lb, st, p, a);
-    else hipLaunchKernelGGL(iql_bwd_lb_kernel<5>, grid, dim3(256), c->lds_bwd_lb, st, p, a);
+    (void)kq;
+    hipLaunchKernelGGL(iql_bwd_rows_kernel, dim3(8 * (a.nbb / 2)), dim3(256), c->lds_bwd_lb, st, p, a);
+    hipLaunchKernelGGL(iql_bwd_gemm_kernel, dim3(8 * ((LB_NJOB * a.n_cg + 1) / 2)), dim3(256), 0, st, p, a);
     return;
   }
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
@@ -826,9 +848,13 @@ static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
   const int nb = 8 * (int)((seg_max + 2047) / 2048);
   const bool peer = u.n_peer > 0;
 #define UPD_LAUNCH(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P>), dim3(nb), dim3(256), 0, st, u)
-  if (u.sched) { if (peer) UPD_LAUNCH(true, true); else UPD_LAUNCH(true, false); }
-  else         { if (peer) UPD_LAUNCH(false, true); else UPD_LAUNCH(false, false); }
+#define UPD_LAUNCH_LB(T) hipLaunchKernelGGL((iql_update_kernel<T, false, true>), dim3(nb), dim3(256), 0, st, u)
+  if (u.slab_x && !peer && !u.flat_grads) {      // large-batch bf16 step (an exchanged gradient arrives flat: the plain kernels)
+    if (u.sched) UPD_LAUNCH_LB(true); else UPD_LAUNCH_LB(false);
+  } else if (u.sched) { if (peer) UPD_LAUNCH(true, true); else UPD_LAUNCH(true, false); }
+  else              { if (peer) UPD_LAUNCH(false, true); else UPD_LAUNCH(false, false); }
 #undef UPD_LAUNCH
+#undef UPD_LAUNCH_LB
 }
 
 // bf16 path: rebuild the bf16 shadows from the fp32 masters (the caller owns the masters and may have written them
@@ -837,12 +863,15 @@ static void refresh_shadows(const iqlhip_ctx* c, hipStream_t st) {
   if (c->precision != 1) return;
   const long long n = std::max<long long>(c->L.n_params, c->L.n_target);
   hipLaunchKernelGGL(iql_shadow_refresh_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, c->params, c->target,
-                     c->wsh, c->tsh, (long long)c->L.n_params, (long long)c->L.n_target);
+                     c->wsh, c->tsh, (long long)c->L.n_params, (long long)c->L.n_target, c->L, c->wimg);
 }
 
 static void launch_flatten(const iqlhip_ctx* c, const UpdParams& u, float* out, bool sys, hipStream_t st) {
   const int nb = (int)((c->L.n_params / 4 + 255) / 256);
-  if (sys) hipLaunchKernelGGL(iql_grad_flatten_kernel<true>, dim3(nb), dim3(256), 0, st, u, out);
+  if (u.slab_x) {
+    if (sys) hipLaunchKernelGGL((iql_grad_flatten_kernel<true, true>), dim3(nb), dim3(256), 0, st, u, out);
+    else hipLaunchKernelGGL((iql_grad_flatten_kernel<false, true>), dim3(nb), dim3(256), 0, st, u, out);
+  } else if (sys) hipLaunchKernelGGL(iql_grad_flatten_kernel<true>, dim3(nb), dim3(256), 0, st, u, out);
   else hipLaunchKernelGGL(iql_grad_flatten_kernel<false>, dim3(nb), dim3(256), 0, st, u, out);
 }
 

@@ -2130,6 +2130,41 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
 }
 
 // ---------------------------------------------------------------------------
+// bf16 OPERAND IMAGES of W1 and W0 (bf16 path; read by the large-batch forward, iqlhip_lb_kernels.h): the weights in the
+// order the MFMA consumes them, so that a wave's fragment load is 1 KB of consecutive memory (with row-major weights the
+// 16 lanes of a group read 16 different rows: the CU's vector-memory pipe handles about one (lane group, cache line)
+// pair per cycle, and the forward's 56 fragment loads per wave cost ~14 k cycles that way).
+//   fragment (slab w = unit >> 6, tile ct = (unit >> 4) & 3, k-block kb = k >> 5): 64 lanes x 8 elements,
+//   lane = (unit & 15) + 16 ((k >> 3) & 3), element = k & 7
+// One image per net slot (V, Q1, Q2, pi, target Q1, target Q2): [W1: 65 536 | W0: 256 x 32 ceil(k_in / 32), zero beyond k_in].
+#define IMG_W0_OFF 65536
+#define IMG_STRIDE (65536 + 256 * 128)
+__device__ __forceinline__ unsigned img_w1_off(int unit, int k) {
+  return (unsigned)((((unit >> 6) * 4 + ((unit >> 4) & 3)) * 8 + (k >> 5)) * 512 + ((unit & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7));
+}
+__device__ __forceinline__ unsigned img_w0_off(int unit, int k, int nkb) {
+  return (unsigned)(IMG_W0_OFF + (((unit >> 6) * 4 + ((unit >> 4) & 3)) * nkb + (k >> 5)) * 512 + ((unit & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7));
+}
+// the four arena elements e .. e + 3 of a net (w1 / w0 offsets and k_in given) -> its image, if they are W1 or W0 elements
+__device__ __forceinline__ void img_store4(__bf16* img, long long e, long long w1, long long w0, int k_in, const f32x4 v) {
+  if (e >= w1 && e < w1 + 65536) {
+    const int idx = (int)(e - w1);
+    bf16x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (__bf16)v[i];
+    *(bf16x4*)(img + img_w1_off(idx >> 8, idx & 255)) = r;
+  } else if (e >= w0 && e < w0 + 256 * k_in) {
+    const int nkb = (k_in + 31) >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = (int)(e - w0) + i;
+      const int unit = idx / k_in, k = idx - unit * k_in;
+      img[img_w0_off(unit, k, nkb)] = (__bf16)v[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Gradient assembly + Adam + Polyak.  Element e (float4 granularity) of the flat arena.
 struct UpdParams {
   iqlhip_layout L;
@@ -2161,8 +2196,12 @@ struct UpdParams {
   float* loss_ring;         // nullable
   int ring_slot;
   int n_chunk, n_rt;        // chunk slabs (slab_a) and row-tile slabs (slab_b) the backward wrote
-  int n_loss;               // 256-row chunks of the batch = entries of loss_parts per loss (the large-batch backward writes
-                            // fewer slabs than chunks: iqlhip_lb_kernels.h)
+  int n_loss;               // entries of loss_parts per loss: 256-row chunks of the batch (large-batch backward: its row blocks)
+  // large-batch backward (iqlhip_lb_kernels.h; LB instantiations only): slab_a holds the row-contraction products (w1, w0, b0,
+  // the policy's w2; n_chunk chunk-group slabs), slab_x the row blocks' partial sums of everything else (b1, scalar w2, b2,
+  // log_std; n_x slabs) — both laid out like the arena
+  const float* slab_x;
+  int n_x;
   int batch_rows;
   const iqlhip_step_scalars* sched;  // when non-null the scalars of this launch are sched[sched_idx]
   int sched_idx;                     // (hipGraph replay: kernel arguments are frozen, the table is not)
@@ -2184,6 +2223,7 @@ struct UpdParams {
   // masters so that the following forward / backward read their W1 fragments at half the bytes; null on the fp32 path
   __bf16* wsh;
   __bf16* tsh;
+  __bf16* wimg;             // bf16 path: operand images [6][IMG_STRIDE] (slots V, Q1, Q2, pi, target Q1, target Q2); nullable
 };
 
 __device__ __forceinline__ int net_of(const iqlhip_layout& L, long long e) {
@@ -2212,6 +2252,7 @@ __device__ __forceinline__ NetWords net_words(const UpdParams& u, int net) {
   return r;
 }
 
+template <bool LB = false>
 __device__ __forceinline__ f32x4 slab_grad(const UpdParams& u, long long e, int net) {
   const NetWords nl = net_words(u, net);
   f32x4 gsum = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -2220,7 +2261,15 @@ __device__ __forceinline__ f32x4 slab_grad(const UpdParams& u, long long e, int 
   const float* base;
   long long stride;
   int n;
-  if (e >= nl.w0 && e < nl.b0 + HID) {
+  if (LB) {
+    // [w1 | w0 | b0 | b1 | w2 | b2 | log_std]: the row contractions (w1, w0, the policy's w2) come from the chunk-group
+    // slabs, every plain sum over rows (the rest) from the row blocks' slabs
+    const long long w2b = nl.b0 + 2 * HID, b2b = w2b + (long long)HID * ((net == IQLHIP_NET_PI) ? u.L.net[IQLHIP_NET_PI].d_out : 1);
+    const bool in_x = (e >= nl.b0) && !(net == IQLHIP_NET_PI && e >= w2b && e < b2b);
+    stride = u.L.n_params;
+    base = (in_x ? u.slab_x : u.slab_a) + e;
+    n = in_x ? u.n_x : u.n_chunk;
+  } else if (e >= nl.w0 && e < nl.b0 + HID) {
     stride = (long long)HID * nl.k_in + HID;
     base = u.slab_b + nl.slab_b_off + (e - nl.w0);
     n = u.n_rt;
@@ -2298,10 +2347,26 @@ __global__ __launch_bounds__(256) void iql_call_setup_kernel(unsigned long long*
 // bf16 shadows rebuilt from the fp32 masters (start of every library call on the bf16 path: the caller owns the
 // masters and may have written them through its own tensors since the last update kernel ran).
 __global__ __launch_bounds__(256) void iql_shadow_refresh_kernel(const float* params, const float* target, __bf16* wsh,
-                                                                 __bf16* tsh, long long n_params, long long n_target) {
+                                                                 __bf16* tsh, long long n_params, long long n_target,
+                                                                 iqlhip_layout L, __bf16* wimg) {
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e < n_params) st4<true>((float*)wsh, (unsigned)e, *(const f32x4*)(params + e));
-  if (e < n_target) st4<true>((float*)tsh, (unsigned)e, *(const f32x4*)(target + e));
+  if (e < n_params) {
+    const f32x4 v = *(const f32x4*)(params + e);
+    st4<true>((float*)wsh, (unsigned)e, v);
+    if (wimg) {
+      const int net = net_of(L, e);
+      img_store4(wimg + (size_t)net * IMG_STRIDE, e, L.net[net].w1, L.net[net].w0, L.net[net].k_in, v);
+    }
+  }
+  if (e < n_target) {
+    const f32x4 v = *(const f32x4*)(target + e);
+    st4<true>((float*)tsh, (unsigned)e, v);
+    if (wimg) {
+      const long long ea = e + L.target_src;       // the element's offset in the parameter arena: nets 1 (Q1), 2 (Q2)
+      const int net = net_of(L, ea);
+      img_store4(wimg + (size_t)(3 + net) * IMG_STRIDE, ea, L.net[net].w1, L.net[net].w0, L.net[net].k_in, v);
+    }
+  }
 }
 
 // Diagnostic (tools/gpu_call_overhead.py): a host-mapped word that says "everything queued before me has run".
@@ -2414,12 +2479,12 @@ __global__ __launch_bounds__(64) void iql_xch_signal_wait_kernel(XchParams x, in
 
 // Writes the summed flat gradient (+ tail: value, q, actor loss contributions, spare) for the DP exchange.
 // SYS: write-through system-scope stores (the buffer is read by peer GPUs).
-template <bool SYS>
+template <bool SYS, bool LB = false>
 __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, float* out) {
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (e < u.L.n_params) {
     const int net = net_of(u.L, e);
-    const f32x4 gv = slab_grad(u, e, net);
+    const f32x4 gv = slab_grad<LB>(u, e, net);
     if (SYS) store16_sys(out + e, gv);
     else *(f32x4*)(out + e) = gv;
   }
@@ -2437,7 +2502,7 @@ __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, floa
 // arguments are frozen, the table is not); otherwise from the kernel argument u.sc.  Two instantiations
 // rather than a run-time pointer select, which would turn every access into a flat load.
 // PEER: the direct-read exchange variant (gradient = rank-ordered sum over UpdParams::peer_flat).
-template <bool FROM_TABLE, bool PEER>
+template <bool FROM_TABLE, bool PEER, bool LB = false>
 __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
   // every kernel-argument word the optimizer path uses, fetched in ONE batch of scalar loads (hipcc otherwise sinks
   // each load next to its first use: five dependent scalar-cache misses in front of the gradient loads).  ONE asm
@@ -2506,7 +2571,7 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
         for (int r = 1; r < IQLHIP_MAX_WORLD; ++r) if (r < u.n_peer) gr += pv[r];
       }
     } else if (u.flat_grads) gr = *(const f32x4*)(u.flat_grads + e);
-    else gr = slab_grad(u, e, net);
+    else gr = slab_grad<LB>(u, e, net);
     const int grp = (net == IQLHIP_NET_V) ? 0 : ((net == IQLHIP_NET_PI) ? 2 : 1);
     // (copy by value: a pointer that may address either the kernarg segment or global memory would make
     //  every access a flat load)
@@ -2536,6 +2601,11 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
       for (int k = 0; k < 4; ++k) t[k] = fmaf(u.tau, pw[k], u.one_minus_tau * t[k]);
       *(f32x4*)tp = t;
       if (u.tsh) st4<true>((float*)u.tsh, (unsigned)(e - u.L.target_src), t);
+    }
+    if (u.wimg) {      // bf16 path: the operand images of W1 / W0 (W1 leads a net's segment)
+      const NetWords nw = net_words(u, net);
+      img_store4(u.wimg + (size_t)net * IMG_STRIDE, e, seg_b, nw.w0, nw.k_in, pw);
+      if (is_q) img_store4(u.wimg + (size_t)(3 + net) * IMG_STRIDE, e, seg_b, nw.w0, nw.k_in, t);      // (nets 1, 2 -> slots 4, 5)
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {

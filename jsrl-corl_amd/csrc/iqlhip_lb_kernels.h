@@ -13,13 +13,19 @@
 //                       the block (all four waves' partial sums meet in LDS) and writes, ONCE per (row, dim), the
 //                       weight-free part of the loss gradient:   T = d(-log pi)/d(pre-tanh) / B,  G = 1 - q,  L = sum_d
 //                       of the log-prob terms — the backward only multiplies them by the row's advantage weight w.
-//   iql_bwd_lb_kernel   (a) blocks: a 32 x 64 tile of dW1 accumulated IN REGISTERS over a group of 256-row chunks (one
-//                       slab per chunk group instead of one per chunk); dY = w * T is loaded, not recomputed; the policy's
-//                       dH1 = dY . W2 and dW2 = dY^T . H1 run on the bf16 MFMA.
-//                       (b) blocks: a strided set of 32-row tiles with the wave's 64 columns of W1 (all 256 k) in
-//                       registers for the whole block; [dW0 | db0] is accumulated in registers over the block's row
-//                       tiles (one slab per block instead of one per row tile).
-//   iql_update_kernel   unchanged: it sums however many slabs the launch wrote.
+//   iql_bwd_rows_kernel block = (net, a strided set of 32-row tiles), the wave's 64 columns of W1 (all 256 k) in registers
+//                       for the whole block.  Per tile: dY = w T (loaded, not recomputed) -> dH1 = (dY . W2) masked ->
+//                       dH0 = (dH1 . W1) masked; dH1, dH0 (and the policy's dY) go to memory as bf16 rows, and everything
+//                       that is a plain sum over the block's rows — db1, the scalar nets' dW2, db2, dlog_std, the loss
+//                       sums — is accumulated in registers and written once per block.
+//   iql_bwd_gemm_kernel every product that contracts over the batch rows — dW1 = dH1^T . H0, [dW0 | db0] = dH0^T . [X | 1],
+//                       the policy's dW2 = dY^T . H1 — as ONE LDS-tiled bf16 GEMM: 64 x 64 output tiles, row-major
+//                       operand tiles copied in with fully coalesced loads, operands transposed on the way out of LDS
+//                       (ds_read_b64_tr_b16), split over chunk groups of rows.  ~64 registers: four blocks per CU.
+//   iql_update_kernel   LB instantiation: sums the chunk-group slabs (w1, w0, b0, policy w2) and the row blocks' slabs.
+// (A first version kept iql_bwd_kernel's shape — dW1 tiles that rebuild dH1 per chunk next to row-tile blocks, in one
+//  launch; with one wave per SIMD its blocks were bound by their own instruction streams: with every load removed the
+//  launch still took 14 of its 23 us at 1 024 rows.)
 //
 // Lane maps (wave64, l15 = lane & 15, g = lane >> 4), v_mfma_f32_16x16x32_bf16:
 //   A[m = l15][k = 8 g + e]   B[k = 8 g + e][n = l15]   D[m = 4 g + reg][n = l15]      (e = 0..7, reg = 0..3)
@@ -31,6 +37,7 @@
 #define LB_SKIP 0           // timing experiments only (wrong results): bit 0 (b) no W1 loads, 1 (a) no H1 / H0 loads, 2 (b) no slab
 #endif                      // store, 3 (a) no T loads, 4 (a) no head loads, 5 (b) no tile loads
 #define LB_DYLD 40          // bf16 row stride of a [rows][32 dims] / [cols][32 rows] tile: 80 bytes, 16-byte aligned rows
+#define LB_XLD 128          // bf16 row stride of the [s | a] copy of the batch (S + A <= 128)
 #define LB_PLD 33           // fp32 row stride of the policy head partials [wave][32 rows][32 dims]
 #define LB_HDLD 28          // fp32 row stride of a chunk's scalar head partials in LDS (24 + 4: 16-byte rows, banks spread)
 
@@ -41,9 +48,17 @@ struct LbArgs {
   int n_rt;         // 32-row tiles of the batch
   int n_chunk;      // 256-row chunks of the batch
   int nbi;          // forward: blocks per instance (even): block ib walks row tiles ib, ib + nbi, ...
-  int nbb;          // backward: (b) blocks per net (even): block lb walks row tiles lb, lb + nbb, ...
-  int cpb;          // backward: chunks per (a) block
+  int nbb;          // backward: row blocks per net (even): block lb walks row tiles lb, lb + nbb, ...
+  int cpb;          // backward: 256-row chunks per GEMM block
   int n_cg;         // backward: chunk groups = ceil(n_chunk / cpb) = chunk slabs written
+  __bf16* dh1g;     // [4][max_batch][256] dL/d(pre-activation of layer 1), masked — rows of the row-contraction GEMMs
+  __bf16* dh0g;     // [4][max_batch][256] the same of layer 0
+  __bf16* dyg;      // [max_batch][32]     the policy's dY = w T
+  __bf16* xbf;      // [max_batch][LB_XLD] the batch's [s | a] columns as bf16 (zero beyond S + A), written by the forward's Q1 blocks
+  float* slab_x;    // [64][n_params]      per row block: partial sums of b1, scalar w2, b2, log_std gradients (arena layout)
+  long long go_w0[4], go_b0[4];      // arena offsets of w0 / b0 per net (the others: StepParams::go)
+  const __bf16* wimg;                // operand images of W1 / W0 (iqlhip_kernels.h), slots V, Q1, Q2, pi, target Q1, target Q2
+  __bf16* w1t;                       // [4][65 536] W1 of the trained nets as the B operand of dH0 = dH1 . W1 (iql_w1t_build)
 };
 
 __device__ __forceinline__ bf16x4 cvt4(const f32x4 v) {
@@ -51,6 +66,30 @@ __device__ __forceinline__ bf16x4 cvt4(const f32x4 v) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) r[i] = (__bf16)v[i];
   return r;
+}
+
+// ---------------------------------------------------------------------------
+// W1 as the B operand of dH0 = dH1 . W1 (contraction over W1's ROW index j): fragment (slab w = i >> 6, tile tb = i & 3,
+// k-block kb = j >> 5), lane = ((i >> 2) & 15) + 16 ((j >> 3) & 3), element = j & 7 — a lane's 8 elements are 8 consecutive
+// j of one column i = 64 w + 4 l15 + tb, i.e. a TRANSPOSE of the row-major weights.  Built once per step from the bf16
+// shadow by the forward's idle eighth (the update kernel's threads own 4 consecutive i of one j: from there it would be
+// four scattered 2-byte stores per thread, ~1.7 us of the chip's vector-memory pipes), read by iql_bwd_rows_kernel.
+// Unit u of 128: (net u >> 5, kb (u >> 2) & 7, w u & 3): 32 rows x 64 columns in, 4 fragments of 1 KB out.
+__device__ __forceinline__ void iql_w1t_build(const StepParams& p, __bf16* w1t, __bf16* stage /* 2 048 elements of LDS */, int blk, int nblk) {
+  const int tid = threadIdx.x;
+  for (int u = blk; u < 128; u += nblk) {
+    const int net = u >> 5, kb = (u >> 2) & 7, w = u & 3;
+    const int jr = tid >> 3, c8 = 8 * (tid & 7);
+    const bf16x8 v = *(const bf16x8*)((const __bf16*)p.net[net].w1 + (unsigned)((32 * kb + jr) * HID + 64 * w + c8));
+    __syncthreads();      // (the previous unit's copy-out has read the stage)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int il = c8 + x;
+      stage[(il & 3) * 512 + (((il >> 2) & 15) + 16 * (jr >> 3)) * 8 + (jr & 7)] = v[x];
+    }
+    __syncthreads();
+    *(bf16x8*)(w1t + (unsigned)(net * 65536 + ((w * 4 + (tid >> 6)) * 8 + kb) * 512 + (tid & 63) * 8)) = *(const bf16x8*)(stage + tid * 8);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -72,7 +111,8 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   const int inst = (int)((((fr & 1) ? FWD_PAIR_B : FWD_PAIR_A) >> (4 * (fx & 3))) & 7u);
   const int nbi = a.nbi;
   const int ib = (fr >> 1) * 2 + fh;
-  if (inst >= 7) {
+  if (inst >= 7) {      // the idle eighth: W1 transposed for the backward; in graph chunks the NEXT step's bookkeeping
+    iql_w1t_build(p, a.w1t, H0b, ib, nbi);
     if (p.g_work) idle_block_work(p.g_work, ib, nbi);
     return;
   }
@@ -103,11 +143,28 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   const bool is_pi = (inst == 6);
   const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
   const bool drop = is_pi && (p.drop_bits != nullptr);
+  bf16x4 xo[NKB];         // the thread's bf16 X values of the current tile (the Q1 instance copies them out)
   const unsigned xtotal = (unsigned)B * (unsigned)ld;
+  // every kernel-argument word the block uses, fetched in one batch now (hipcc sinks each scalar load next to its first
+  // use: a dependent ~500-cycle fetch in front of each phase otherwise)
+  __bf16* h0g = (__bf16*)p.sc.h0;
+  __bf16* h1g = (__bf16*)p.sc.h1;
+  float* headsg = p.sc.heads;
+  const float invB = p.inv_batch;
+  const float ls_min = p.hy.log_std_min, ls_max = p.hy.log_std_max, drop_scale = p.drop_scale;
+  const unsigned* drop_bits = p.drop_bits;
+  const float* log_std = p.log_std;
+  float* pi_t = a.pi_t; float* pi_g = a.pi_g; float* pi_l = a.pi_l;
+  __bf16* xbf = a.xbf;
+  PIN_P(np.w0); PIN_P(np.b0); PIN_P(np.w1); PIN_P(np.b1); PIN_P(np.w2); PIN_P(np.b2);
+  PIN_S(k0); PIN_S(D); PIN_S(xoff); PIN_S(slot); PIN_S(ld); PIN_S(B); PIN_S(MB); PIN_S(S); PIN_S(A); PIN_S(n_rt); PIN_S(nbi);
+  PIN_P(xb); PIN_P(h0g); PIN_P(h1g); PIN_P(headsg); PIN_P(drop_bits); PIN_P(log_std); PIN_P(pi_t); PIN_P(pi_g); PIN_P(pi_l); PIN_P(xbf);
+  PIN_S(invB); PIN_S(ls_min); PIN_S(ls_max); PIN_S(drop_scale);
 
   // ---- the 32 packed rows of a tile: thread (row tid >> 3, float4 (tid & 7) + 8 q of the instance's input columns)
   const int xr = tid >> 3, xc = tid & 7;
   f32x4 xv[NKB];
+  int x_row = 0;          // the batch row this thread's X values belong to (x_store)
   auto x_issue = [&](int rt) {
     const unsigned row = (unsigned)min(rt * RT_ROWS + xr, B - 1);
 #pragma unroll
@@ -137,6 +194,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (__bf16)((c + j < k0) ? xv[q][j] : 0.f);     // columns >= k0: other fields of the row
         *(bf16x4*)(Xb + xr * XLD + c) = o;
+        xo[q] = o;
       }
     }
   };
@@ -145,22 +203,17 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   STAMP(p, 0);
   x_issue(rt);
 
-  // ---- the wave's operands for the whole block.  Layer 0: A = W0 rows of units 64 w + 16 ct + l15 (fp32 master, k = 32 kb
-  // + 8 g + e; the last k-block reads past k0 into the next row / the bias that follows — finite values against zero X)
-  // (k-blocks beyond the instance's own are loaded from its last one — never used: no branch around a load)
-  f32x4 w0lo[4][NKB], w0hi[4][NKB];
+  // ---- the wave's operands for the whole block, from the net's operand image (fragment-major bf16: a fragment load is
+  // 1 KB of consecutive memory).  Layer 0: A = W0 rows of units 64 w + 16 ct + l15, k = 32 kb + 8 g + e (zero beyond k0;
+  // k-blocks beyond the instance's own are loaded from its last one — never used: no branch around a load)
+  constexpr unsigned IMG_SLOT = 0x3215400u;       // instance -> image slot: V(s') V(s) Qt1 Qt2 Q1 Q2 pi -> 0 0 4 5 1 2 3
+  const __bf16* img = a.wimg + (size_t)((IMG_SLOT >> (4 * inst)) & 7u) * IMG_STRIDE;
+  bf16x8 w0f[4][NKB];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-#ifdef LB_HACK_FRAG      // timing only (wrong values): the loads of a fragment-major image
-      const float* src = np.w0 + (unsigned)(((((wv * 4 + ct) * nkb + min(kb, nkb - 1)) * 64 + lane) * 8) % (256 * k0 - 8));
-#else
-      const float* src = np.w0 + (unsigned)((64 * wv + 16 * CP(ct) + l15) * k0 + 32 * min(kb, nkb - 1) + 8 * g);
-#endif
-      w0lo[ct][kb] = *(const f32x4u*)src;
-      w0hi[ct][kb] = *(const f32x4u*)(src + 4);
-    }
+    for (int kb = 0; kb < NKB; ++kb)
+      w0f[ct][kb] = *(const bf16x8*)(img + (unsigned)(IMG_W0_OFF + (((wv * 4 + CP(ct)) * nkb + min(kb, nkb - 1)) * 64 + lane) * 8));
   f32x4 bias0[4], bias1[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
@@ -186,7 +239,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   const float b2s = np.b2[0];
   // policy: the thread's (row tid >> 3, dims (tid & 7) + 8 c) constants
   float b2v[4], lsr[4];
-  const float* lsp = (is_pi && gauss) ? p.log_std : np.b2;      // (any valid address when unused)
+  const float* lsp = (is_pi && gauss) ? log_std : np.b2;      // (any valid address when unused)
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int d = min(xc + 8 * c, D - 1);
@@ -200,16 +253,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
-#ifdef LB_HACK_FRAG
-      w1f[ct][kb] = *(const bf16x8*)((const __bf16*)np.w1 + (unsigned)((((wv * 4 + ct) * 8 + kb) * 64 + lane) * 8));
-#else
-      w1f[ct][kb] = *(const bf16x8*)((const __bf16*)np.w1 + (unsigned)((64 * wv + 16 * CP(ct) + l15) * HID + 32 * KP(kb) + 8 * g));
-#endif
-  bf16x8 w0f[4][NKB];
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) w0f[ct][kb] = pack8(w0lo[ct][kb], w0hi[ct][kb]);
+      w1f[ct][kb] = *(const bf16x8*)(img + (unsigned)((((wv * 4 + CP(ct)) * 8 + KP(kb)) * 64 + lane) * 8));
   bf16x8 w2f[2][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -218,15 +262,10 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   float ivar[4], lsc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    lsc[c] = (is_pi && gauss) ? fminf(fmaxf(lsr[c], p.hy.log_std_min), p.hy.log_std_max) : 0.f;
+    lsc[c] = (is_pi && gauss) ? fminf(fmaxf(lsr[c], ls_min), ls_max) : 0.f;
     const float sig = expf(lsc[c]);
     ivar[c] = 1.f / (sig * sig);
   }
-
-  __bf16* h0g = (__bf16*)p.sc.h0;
-  __bf16* h1g = (__bf16*)p.sc.h1;
-  float* headsg = p.sc.heads;
-  const float invB = p.inv_batch;
 
   STAMP(p, 1);
   for (; rt < n_rt; rt += nbi) {
@@ -241,7 +280,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
       const unsigned prow = (unsigned)min(row0 + xr, B - 1);
 #pragma unroll
       for (int c = 0; c < 4; ++c) pac[c] = xb[prow * (unsigned)ld + (unsigned)(S + min(xc + 8 * c, A - 1))];
-      const unsigned* dbits = drop ? p.drop_bits : (const unsigned*)xb;
+      const unsigned* dbits = drop ? drop_bits : (const unsigned*)xb;
       const unsigned mb_off = drop ? (unsigned)MB : 0u;
 #pragma unroll
       for (int r2 = 0; r2 < 2; ++r2)
@@ -252,6 +291,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
           dm1[r2][ws] = dbits[(mb_off + mrow) * 8u + (unsigned)(2 * wv + ws)];
         }
     }
+    x_row = row0 + xr;
     x_store();
     __syncthreads();
     if (first) STAMP(p, 2);
@@ -286,7 +326,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
           if (drop) {      // units 64 wv + 16 CP(ct) + 4 g .. + 3 of row 16 r2 + l15
             const unsigned bits = ((CP(ct) >> 1) ? dm0[r2][1] : dm0[r2][0]) >> ((CP(ct) & 1) * 16 + 4 * g);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) h[reg] = ((bits >> reg) & 1u) ? h[reg] * p.drop_scale : 0.f;
+            for (int reg = 0; reg < 4; ++reg) h[reg] = ((bits >> reg) & 1u) ? h[reg] * drop_scale : 0.f;
           }
           *(bf16x4*)(H0b + (16 * r2 + l15) * H0B_LD + 64 * wv + 16 * CP(ct) + 4 * g) = cvt4(h);
         }
@@ -335,7 +375,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
           if (drop) {
             const unsigned bits = ((CP(ct) >> 1) ? dm1[r2][1] : dm1[r2][0]) >> ((CP(ct) & 1) * 16 + 4 * g);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) h1[r2][ct][reg] = ((bits >> reg) & 1u) ? h1[r2][ct][reg] * p.drop_scale : 0.f;
+            for (int reg = 0; reg < 4; ++reg) h1[r2][ct][reg] = ((bits >> reg) & 1u) ? h1[r2][ct][reg] * drop_scale : 0.f;
           }
         }
     }
@@ -418,11 +458,18 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
       if (row < B) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          a.pi_t[(unsigned)(row * 32 + xc + 8 * c)] = tv[c];
-          a.pi_g[(unsigned)(row * 32 + xc + 8 * c)] = gv[c];
+          pi_t[(unsigned)(row * 32 + xc + 8 * c)] = tv[c];
+          pi_g[(unsigned)(row * 32 + xc + 8 * c)] = gv[c];
         }
-        if (xc == 0) a.pi_l[row] = lsum;
+        if (xc == 0) pi_l[row] = lsum;
       }
+    }
+    // the Q1 instance reads [s | a], i.e. every net's layer-0 input: its bf16 rows are the operand of dW0 = dH0^T . X
+    // (stored last in the tile: a store in front of the barriers sits in front of every later load in the in-order vmcnt)
+    if (inst == 4 && x_row < B) {
+#pragma unroll
+      for (int q = 0; q < NKB; ++q)
+        if (q < nkb) *(bf16x4*)(xbf + (unsigned)(x_row * LB_XLD + 4 * (xc + 8 * q))) = xo[q];
     }
     if (first) STAMP(p, 8);
   }
@@ -434,653 +481,445 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// Backward.  grid = 8 x ceil((32 n_cg + nbb) / 2); blockIdx & 7 = x: net = x & 3, parity = x >> 2 (XCD n + 4 parity).  Within a
-// net the (b) blocks come first (they are the long ones), then the dW1 tiles.
-// NCT: 16-wide tiles of [dW0 | db0]'s kc range a (b) block accumulates in registers (k_in + 1 <= 16 NCT).
-// Both kinds of block request the inputs of their NEXT chunk / row tile before they work on the current one (vmcnt
-// retires in order, so the work never waits for the prefetch), and nothing is loaded behind a branch that the
-// compiler would have to wait in front of.
+// Backward, rows.  grid = 8 x nbb / 2; blockIdx & 7 = x: net = x & 3, block lb = 2 (blockIdx >> 3) + (x >> 2) on XCD n + 4 (lb & 1)
+// — the XCD whose forward blocks wrote the H0 / H1 rows of tiles of that parity.
 // (Load shapes: the CU's vector-memory pipe handles about one (16-lane group, cache line) pair per cycle, so the 16 lanes
-//  of a group should read one contiguous run.  The per-row head partials — 96 bytes per row, a row per lane: 12 lines per
-//  group and instruction — are therefore fetched as a flat, fully coalesced copy and redistributed through LDS.)
-struct LbChunkIn {        // what a dW1-tile block loads per 256-row chunk
-  f32x4 hq[6];            // the chunk's scalar head partials [256 rows][24] as a flat copy: float4 tid + 256 q
-  float r, d;             // Q nets: the thread's row's reward / done
-  f32x4 tq[8];            // policy: T of (rows (tid + 256 q) >> 3, dims 4 ((tid + 256 q) & 7) ..)
-  float lrow;             // policy, loss block: L of the thread's row
-  bf16x2 hh[16];          // H1[row AROW(ks)][j0 + 2 l15 ..]
-  bf16x4 bb[16];          // H0[row AROW(ks)][i0 + 4 l15 ..]
-};
-struct LbTileIn {         // what a (b) block loads per 32-row tile
+//  of a group read one contiguous run wherever possible; tiles needed in an MFMA accumulator layout — the H1 mask — are
+//  fetched as flat copies and redistributed through LDS.  Nothing is loaded behind a branch the compiler would wait at.)
+struct LbTileIn {         // what a row block loads per 32-row tile
   RowIn in;               // scalar nets, wave 0: the row's loss inputs
-  f32x4 ph[3], t4;        // policy: V / Qt1 / Qt2 partials of row tid >> 3, T of dims 4 (tid & 7) ..
+  f32x4 ph[3], t4, g4;    // policy: V / Qt1 / Qt2 partials of row tid >> 3, T and G of dims 4 (tid & 7) ..
+  float lrow;             // policy: L of row tid >> 3
   bf16x8 h1q[4];          // the H1 tile [32][256] as a flat copy: 16 bytes tid + 256 q (-> LDS -> dH1's accumulator layout)
   bf16x4 hm[2][4];        // H0 in dH0's accumulator layout
-  f32x4 xq[3];            // X of (row tid >> 3, columns 4 ((tid & 7) + 8 q) ..)
 };
-template <int NCT>
-__global__ __launch_bounds__(256) void iql_bwd_lb_kernel(StepParams p, LbArgs a) {
+__global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RT_ENTRY();
   const int bid = blockIdx.x;
   const int x = bid & 7;
   const int net = x & 3;
-  const int local_ = (bid >> 3) * 2 + (x >> 2);
-  const int n_a = 32 * a.n_cg, n_b = a.nbb;
-  if (local_ >= n_a + n_b) return;
+  const int lb = (bid >> 3) * 2 + (x >> 2);
+  if (lb >= a.nbb) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int B = p.rows, MB = p.sc.max_batch, ld = p.ld;
+  const int B = p.rows, MB = p.sc.max_batch;
   const NetPtrs np = p.net[net];
   const NetGrad go = p.go[net];
-  const int D = np.d, k0 = np.k0;
+  const int D = np.d;
   const bool is_pi = (net == IQLHIP_NET_PI);
   const bool gauss = (p.policy == IQLHIP_POLICY_GAUSSIAN);
   const float* w2 = np.w2;
-  const float* H1g = (const float*)((const __bf16*)p.sc.h1 + net * MB * HID);      // (bf16 arrays, read through ld4 / ld2)
-  const float* H0g = (const float*)((const __bf16*)p.sc.h0 + net * MB * HID);
+  const __bf16* H1g = (const __bf16*)p.sc.h1 + net * MB * HID;
+  const __bf16* H0g = (const __bf16*)p.sc.h0 + net * MB * HID;
+  __bf16* dH1g = a.dh1g + net * MB * HID;
+  __bf16* dH0g = a.dh0g + net * MB * HID;
   const float* heads = p.sc.heads;
-  const float* xb = p.xb;
   const float dscale = (is_pi && p.drop_bits != nullptr) ? p.drop_scale : 1.f;
   const float invB = p.inv_batch;
+  // every kernel-argument word the block uses, fetched in one batch now (cf. iql_fwd_lb_kernel)
+  const float* pi_t = a.pi_t; const float* pi_g = a.pi_g; const float* pi_l = a.pi_l;
+  __bf16* dyg = a.dyg;
+  float* slabX = a.slab_x + (long long)lb * p.n_params;      // this block's slab of sums (arena layout)
+  const long long go_b0 = a.go_b0[net];
+  const float* log_std = p.log_std;
+  const __bf16* w1t = a.w1t + net * 65536;
+  const float ls_min = p.hy.log_std_min, ls_max = p.hy.log_std_max, beta = p.hy.beta, adv_max = p.hy.exp_adv_max;
+  float* loss_parts = p.sc.loss_parts;
+  const int n_rt = a.n_rt, nbb = a.nbb;
+  PIN_P(pi_t); PIN_P(pi_g); PIN_P(pi_l); PIN_P(dyg); PIN_P(slabX); PIN_P(log_std); PIN_P(loss_parts); PIN_P(w2); PIN_P(w1t);
+  PIN_P(H1g); PIN_P(H0g); PIN_P(dH1g); PIN_P(dH0g); PIN_P(heads); PIN_P(p.xb);
+  PIN_S(go_b0); PIN_S(go.b1); PIN_S(go.w2); PIN_S(go.b2); PIN_S(go.log_std); PIN_S(ls_min); PIN_S(ls_max); PIN_S(beta); PIN_S(adv_max);
+  PIN_S(dscale); PIN_S(invB); PIN_S(n_rt); PIN_S(nbb); PIN_S(B); PIN_S(D); PIN_S(p.ld); PIN_S(p.S); PIN_S(p.A);
+  PIN_S(p.hy.iql_tau); PIN_S(p.hy.discount);
 #define LBROW(r) min((r), B - 1)
   STAMP_BASE(p, 2048 * 16);
   STAMP(p, 0);
-
-  if (local_ >= n_b) {
-    // ===================== (a): dW1[32 j][64 i] over the chunks of one chunk group =====================
-    const int la = local_ - n_b;
-    const int cg = la >> 5, jt = (la >> 2) & 7, it = la & 3;
-    const int j0 = jt * 32, i0 = it * 64;
-    float* red = smem;                                   // [4][32][T64_LD]
-    __bf16* dYb = (__bf16*)(red + 4 * 32 * T64_LD);      // [256][LB_DYLD]  dY of the chunk (policy), rows x dims
-    __bf16* dYT = dYb + CHUNK_ROWS * LB_DYLD;            // [32][H0B_LD]    the same, dims x rows (dW2 blocks)
-    float* wS = (float*)(dYT + 32 * H0B_LD);             // [256] per-row weight (policy) / dy (scalar nets)
-    float* hdS = wS + CHUNK_ROWS;                        // [256][LB_HDLD] the chunk's scalar head partials
-    float* part = hdS + CHUNK_ROWS * LB_HDLD;            // [2][32][32] column-sum partials of dY and w G (designated block)
-    float* exA = part + 2 * 32 * 32;                     // [16][64]
-    float* rsm = exA + 16 * 64;                          // [64]
-    float* exB = (float*)dYb;                            // [4][32][32] (after the last chunk: dYb is dead)
-    const bool designated = (jt == 0 && it == 2);
-    const bool loss_block = (jt == 1 && it == 2);
-    const bool do_db1 = (it == 0);
-    const bool do_dw2 = is_pi ? (it == 1 || it == 3) : (it == 0);
-    const int tb_own = (it == 3) ? 1 : 0;
-    const bool extras = do_db1 || do_dw2;
-    const int ndt = (D + 15) >> 4;
-    const bool is_q = (net == IQLHIP_NET_Q1 || net == IQLHIP_NET_Q2);
-    float* slab = p.sc.slab_a + (long long)cg * p.n_params;
-#define AROW(ks) (64 * wave + 16 * ((ks) >> 2) + 4 * g + ((ks) & 3))
-    auto issue = [&](LbChunkIn& s, int c) {
-      const int cbase = c * CHUNK_ROWS;
-      {
-        const unsigned hmax = (unsigned)B * 6u - 1u;      // last float4 of the batch's head partials
+  __bf16* dH1b = (__bf16*)smem;                        // [32][H0B_LD]  dH1 tile (dH0's A operand; copied out to dH1g)
+  __bf16* H1t = dH1b + 32 * H0B_LD;                    // [32][H0B_LD]  H1 tile (mask of dH1; the scalar nets' dW2 operand)
+  __bf16* dH0b = H1t + 32 * H0B_LD;                    // [32][H0B_LD]  dH0 tile on its way to dH0g
+  __bf16* dYb = dH0b + 32 * H0B_LD;                    // [32][LB_DYLD] dY of the tile (policy)
+  float* dys = (float*)(dYb + 32 * LB_DYLD);           // [32] dy of the tile (scalar nets)
+  const int xr = tid >> 3, xc = tid & 7;
+  auto issue = [&](LbTileIn& s, int rt) {
+    const int row0 = rt * RT_ROWS;
+    if (wave == 0) row_issue(p, LBROW(row0 + (tid & 31)), s.in);
+    const unsigned prow = (unsigned)LBROW(row0 + xr);
+    const unsigned oh = prow * (unsigned)HEAD_LD;
+    s.ph[0] = *(const f32x4*)(heads + (oh + 4u)); s.ph[1] = *(const f32x4*)(heads + (oh + 8u)); s.ph[2] = *(const f32x4*)(heads + (oh + 12u));
+    s.t4 = *(const f32x4*)(pi_t + (prow * 32u + 4u * (unsigned)xc));
+    s.g4 = *(const f32x4*)(pi_g + (prow * 32u + 4u * (unsigned)xc));
+    s.lrow = pi_l[prow];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          if (LB_SKIP & 16) s.hq[q] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
-          else s.hq[q] = *(const f32x4*)(heads + 4u * min((unsigned)cbase * 6u + (unsigned)(tid + 256 * q), hmax));
-        }
-        s.r = 0.f; s.d = 0.f;
-        if (is_q) {
-          const unsigned ox = (unsigned)LBROW(cbase + tid) * (unsigned)ld + (unsigned)(2 * p.S + p.A);
-          s.r = xb[ox];
-          s.d = xb[ox + 1u];
-        }
-      }
-      if (is_pi) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int f = tid + 256 * q;
-          if (LB_SKIP & 8) s.tq[q] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
-          else s.tq[q] = *(const f32x4*)(a.pi_t + (unsigned)(LBROW(cbase + (f >> 3)) * 32 + 4 * (f & 7)));
-        }
-        s.lrow = a.pi_l[LBROW(cbase + tid)];
-      }
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const unsigned row = (unsigned)LBROW(cbase + AROW(ks));
-        if (LB_SKIP & 2) {
-          s.hh[ks] = (bf16x2){(__bf16)1.f, (__bf16)0.f};
-          s.bb[ks] = (bf16x4){(__bf16)1.f, (__bf16)0.f, (__bf16)2.f, (__bf16)0.f};
-        } else {
-          s.hh[ks] = ld2<true>(H1g, row * (unsigned)HID + (unsigned)(j0 + 2 * l15));
-          s.bb[ks] = ld4<true>(H0g, row * (unsigned)HID + (unsigned)(i0 + 4 * l15));
-        }
-      }
-    };
-    const int c0 = cg * a.cpb, c_end = min((cg + 1) * a.cpb, a.n_chunk);
-    LbChunkIn SA, SB;
-    if (!is_pi) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { SA.tq[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; SB.tq[q] = SA.tq[q]; }
-      SA.lrow = 0.f; SB.lrow = 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int f = tid + 256 * q;
+      s.h1q[q] = *(const bf16x8*)(H1g + ((unsigned)LBROW(row0 + (f >> 5)) * (unsigned)HID + (unsigned)(8 * (f & 31))));
     }
-    issue(SA, c0);
-    // W2 of this j tile, straight from memory in operand layout.  Scalar nets: the lane's two columns.  Policy: the B
-    // operand of dH1 = dY . W2 (k = dim 8 g + e, n = j = 2 l15 + ta), in registers for the whole block
-    f32x2 wq[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wq[e] = *(const f32x2*)(w2 + (unsigned)(min(8 * g + e, D - 1) * HID + j0 + 2 * l15));
-    const float w2a = wq[0][0], w2b = wq[0][1];      // (D == 1: every e reads row 0)
-    bf16x8 W2B[2];
+    for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-    for (int ta = 0; ta < 2; ++ta) {
-      float t8[8];
+      for (int reg = 0; reg < 4; ++reg)
+        s.hm[r2][reg] = *(const bf16x4*)(H0g + ((unsigned)LBROW(row0 + 16 * r2 + 4 * g + reg) * (unsigned)HID + (unsigned)(64 * wave + 4 * l15)));
+  };
+  LbTileIn T;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) t8[e] = (8 * g + e < D) ? wq[e][ta] : 0.f;
-      W2B[ta] = pack8s(t8);
-    }
-    f32x4 acc[2][4];
+  for (int i = 0; i < 6; ++i) T.in.h[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  T.in.r = 0.f; T.in.d = 0.f;
+  issue(T, lb);
+  // (the raw log_std of dim tid, for the block's last lines: loaded HERE, with the first batch — left at its use the
+  //  compiler hoists the load in front of the tile loop and waits for everything in flight, the whole W1 stream, there)
+  const float lsr_e = ((is_pi && gauss) ? log_std : w2)[min(tid, D - 1)];
+  // ---- the wave's operands for the whole block (requested BEHIND the first tile's inputs: the loss arithmetic and the
+  // dH1 tile run under this stream)
+  // W2: scalar nets — the lane's 16 columns j = 64 w + 16 jt + 4 g + reg; policy — A operand of dH1^T = W2^T . dY^T
+  // (m = j = 64 w + 16 jt + l15, k = dim 8 g + e)
+  f32x4 w2q[4];
+  float w2s[4][8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int jt = 0; jt < 4; ++jt) {
+    w2q[jt] = *(const f32x4*)(w2 + (unsigned)(64 * wave + 16 * jt + 4 * g));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 acc2[2];      // policy dW2 tiles [dt] of the lane's column tb_own
-    acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc2[1] = acc2[0];
-    float db1a[2] = {0.f, 0.f}, dw2a[2] = {0.f, 0.f};
-    float tot_b2 = 0.f, tot_ls = 0.f;      // designated block: thread d (< 32) accumulates db2[d] / dlog_std[d] over the chunks
-    STAMP(p, 1);
-
-    auto compute = [&](LbChunkIn& s, int c) {
-      const int cbase = c * CHUNK_ROWS;
-      const bool first = (c == c0);
-      const int prow = cbase + tid;
-      // the policy's dlog_std terms: one block in 32 needs them — loaded here, not prefetched
-      f32x4 gq[8];
-      if (is_pi && designated && gauss) {
+    for (int e = 0; e < 8; ++e) w2s[jt][e] = w2[(unsigned)(min(8 * g + e, D - 1) * HID + 64 * wave + 16 * jt + l15)];
+  }
+  // W1 as the B operand of dH0 = dH1 . W1 (k = j = 32 kb + 8 g + e, n = column 64 w + 4 l15 + tb), from the transposed
+  // image the forward's idle blocks built (iql_w1t_build): a fragment load is 1 KB of consecutive memory
+  bf16x8 bwf[4][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int f = tid + 256 * q;
-          gq[q] = *(const f32x4*)(a.pi_g + (unsigned)(LBROW(cbase + (f >> 3)) * 32 + 4 * (f & 7)));
-        }
-      }
-      // ---- the flat copy of the head partials -> [row][24] in LDS -> the thread's own row
+  for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int f = tid + 256 * q;
-        *(f32x4*)(hdS + (f / 6) * LB_HDLD + 4 * (f % 6)) = s.hq[q];
-      }
-      __syncthreads();
-      // ---- per row: dy of a scalar head, or the policy's advantage weight
-      float lossA = 0.f, lossB = 0.f;
-      {
-        RowIn in;
+    for (int kb = 0; kb < 8; ++kb)
+      bwf[tb][kb] = *(const bf16x8*)(w1t + (unsigned)((((wave * 4 + tb) * 8 + kb) * 64 + lane) * 8));
+  bf16x8 w2A[4];      // (packed behind the first tile's first barrier: its inputs are the last small loads to arrive)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) in.h[i] = *(const f32x4*)(hdS + tid * LB_HDLD + 4 * i);
-        in.r = s.r; in.d = s.d;
-        float v = 0.f;
-        if (prow < B) {
-          if (!is_pi) {
-            row_finish(p, net, in, &v, lossA, lossB);
-          } else {
-            const float tqv = fminf(sum4(in.h[2]), sum4(in.h[3]));
-            const float u = tqv - sum4(in.h[1]);
-            v = fminf(expf(p.hy.beta * u), p.hy.exp_adv_max);
-            lossA = v * s.lrow;
-          }
-        }
-        wS[tid] = v;
-      }
-      if (first) STAMP(p, 2);
-      __syncthreads();
-      if (first) STAMP(p, 3);
-      if (loss_block) {
-        const float sA = block_sum_256(lossA, rsm);
-        if (net == IQLHIP_NET_V && tid == 0) p.sc.loss_parts[0 * 64 + c] = sA;
-        if (net == IQLHIP_NET_PI && tid == 0) p.sc.loss_parts[3 * 64 + c] = sA;
-        if (net == IQLHIP_NET_Q1) {
-          const float sB = block_sum_256(lossB, rsm + 8);
-          if (tid == 0) { p.sc.loss_parts[1 * 64 + c] = sA; p.sc.loss_parts[2 * 64 + c] = sB; }
-        }
-      }
-      if (is_pi) {
-        // dY = w T of the chunk -> bf16 [row][dim] (dH1's A operand) and, dW2 blocks, [dim][row] (dW2's A operand)
-        f32x4 csum = (f32x4){0.f, 0.f, 0.f, 0.f}, gsum = csum;
+  for (int jt = 0; jt < 4; ++jt) w2A[jt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  // the block's sums over its rows
+  f32x4 db1p[4], dw2p[4];       // the lane's columns 64 w + 16 jt + 4 g .., over the rows its accumulators hold
+  f32x4 db0p = (f32x4){0.f, 0.f, 0.f, 0.f};      // the lane's columns 64 w + 4 l15 + tb of dH0, over its rows
+  f32x4 pb2 = (f32x4){0.f, 0.f, 0.f, 0.f}, pls = pb2;      // policy: dims 4 xc .. over rows xr of the block's tiles
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int f = tid + 256 * q;
-          const int r = f >> 3, c4 = f & 7;
-          const float w = wS[r];
-          const f32x4 v = s.tq[q] * w;
-          *(bf16x4*)(dYb + r * LB_DYLD + 4 * c4) = cvt4(v);
-          if (do_dw2) {
+  for (int jt = 0; jt < 4; ++jt) { db1p[jt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dw2p[jt] = db1p[jt]; }
+  float accA = 0.f, accB = 0.f, accb2 = 0.f;      // loss sums (scalar nets: threads < 32; policy: threads xc == 0), scalar db2
+  // ---- the block's sums -> its slab (arena layout).  Run in FRONT of the last tile's dH0 copy-out (LDS region of its own):
+  // behind it, the first registers it touches were the copy-out stores' sources, and the block waited ~4 k cycles for
+  // those stores to complete before it even started — and then once more for its own stores at the end of the kernel.
+  auto block_sums = [&]() {
+  float* part1 = (float*)(dys + 32);   // [16][260] db1 partials by the lanes' l15 (260: the 16 rows a write touches spread over the banks)
+  float* part2 = part1 + 16 * 260;     // [16][260] scalar dW2 partials
+  float* pip = part2 + 16 * 260;       // [2][32][32] policy db2 / dlog_std partials by xr
+  float* part0 = pip + 2 * 32 * 32;    // [4][256] db0 partials by the lanes' g
+  float* rsm = part0 + 4 * 256;        // [16]
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dYT[(4 * c4 + j) * H0B_LD + r] = (__bf16)v[j];
-          }
-          if (designated) {
-            csum += v;
-            if (gauss) gsum += gq[q] * w;
-          }
-        }
-        if (designated) {       // thread (row group tid >> 3, dims 4 (tid & 7) ..): its 8 rows' sums
-          *(f32x4*)(part + (tid >> 3) * 32 + 4 * (tid & 7)) = csum;
-          *(f32x4*)(part + 1024 + (tid >> 3) * 32 + 4 * (tid & 7)) = gsum;
-        }
-        __syncthreads();
-        if (designated && tid < 32) {
-          float sb = 0.f, sl = 0.f;
+  for (int jt = 0; jt < 4; ++jt) {
+    *(f32x4*)(part1 + l15 * 260 + 64 * wave + 16 * jt + 4 * g) = db1p[jt];
+    *(f32x4*)(part2 + l15 * 260 + 64 * wave + 16 * jt + 4 * g) = dw2p[jt];
+  }
+  *(f32x4*)(part0 + g * 256 + 64 * wave + 4 * l15) = db0p;
+  *(f32x4*)(pip + xr * 32 + 4 * xc) = pb2;
+  *(f32x4*)(pip + 1024 + xr * 32 + 4 * xc) = pls;
+  __syncthreads();
+  {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { s1 += part1[l * 260 + tid]; s2 += part2[l * 260 + tid]; }
+    slabX[go.b1 + tid] = s1;
+    if (!is_pi) slabX[go.w2 + tid] = s2;
+    slabX[go_b0 + tid] = (part0[tid] + part0[256 + tid]) + (part0[512 + tid] + part0[768 + tid]);
+  }
+  if (is_pi) {
+    if (tid < D) {
+      float sb = 0.f, sl = 0.f;
 #pragma unroll 8
-          for (int k = 0; k < 32; ++k) { sb += part[k * 32 + tid]; sl += part[1024 + k * 32 + tid]; }
-          tot_b2 += sb;
-          tot_ls += sl;
-        }
-      } else if (designated && wave == 0) {
-        float sb = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sb += wS[lane + 64 * q];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sb += __shfl_xor(sb, o);
-        tot_b2 += sb;
-      }
-      if (first) STAMP(p, 4);
-      // ---- operand phase: av[ks][ta] = dH1[row AROW(ks)][j0 + 2 l15 + ta]
-      float av[16][2];
-      if (!is_pi) {
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const float dy = wS[AROW(ks)];
-          av[ks][0] = ((float)s.hh[ks][0] > 0.f) ? dy * w2a * dscale : 0.f;
-          av[ks][1] = ((float)s.hh[ks][1] > 0.f) ? dy * w2b * dscale : 0.f;
-          if (do_dw2) {
-            dw2a[0] = fmaf(dy, (float)s.hh[ks][0], dw2a[0]);
-            dw2a[1] = fmaf(dy, (float)s.hh[ks][1], dw2a[1]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const bf16x8 Ad = *(const bf16x8*)(dYb + (64 * wave + 16 * t + l15) * LB_DYLD + 8 * g);
-          const f32x4 p0 = MFMA_BF16(Ad, W2B[0], ((f32x4){0.f, 0.f, 0.f, 0.f}));
-          const f32x4 p1 = MFMA_BF16(Ad, W2B[1], ((f32x4){0.f, 0.f, 0.f, 0.f}));
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            av[4 * t + reg][0] = ((float)s.hh[4 * t + reg][0] > 0.f) ? p0[reg] * dscale : 0.f;
-            av[4 * t + reg][1] = ((float)s.hh[4 * t + reg][1] > 0.f) ? p1[reg] * dscale : 0.f;
-          }
-        }
-      }
-      if (do_db1) {
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) { db1a[0] += av[ks][0]; db1a[1] += av[ks][1]; }
-      }
-      if (first) STAMP(p, 5);
-      // ---- dW1 += dH1^T . H0 over the chunk's 256 rows: k index e of k-block q = row AROW(8 q + e) on both operands
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        bf16x8 Aop[2], Bv[4];
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta) {
-          float t8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) t8[e] = av[8 * q + e][ta];
-          Aop[ta] = pack8s(t8);
-        }
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) Bv[tb][e] = s.bb[8 * q + e][tb];
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-          for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = MFMA_BF16(Aop[ta], Bv[tb], acc[ta][tb]);
-      }
-      if (is_pi && do_dw2) {
-        // dW2[dim][j] += dY^T . H1: A = dY^T (m = dim 16 dt + l15, k = row), B = H1 (n = the lane's column tb_own)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          bf16x8 Bh;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) Bh[e] = s.hh[8 * q + e][tb_own];
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            if (dt < ndt) {
-              const __bf16* src = dYT + (16 * dt + l15) * H0B_LD + 64 * wave + 32 * q + 4 * g;
-              const bf16x8 Ay = cat8(*(const bf16x4*)src, *(const bf16x4*)(src + 16));
-              acc2[dt] = MFMA_BF16(Ay, Bh, acc2[dt]);
-            }
-          }
-        }
-      }
-      if (first) STAMP(p, 6);
-      __syncthreads();      // every thread has left this chunk's LDS tiles
-      if (first) STAMP(p, 7);
-    };
-    for (int c = c0; c < c_end; c += 2) {
-      if (c + 1 < c_end) issue(SB, c + 1);
-      compute(SA, c);
-      if (c + 1 < c_end) {
-        if (c + 2 < c_end) issue(SA, c + 2);
-        compute(SB, c + 1);
+      for (int r = 0; r < 32; ++r) { sb += pip[r * 32 + tid]; sl += pip[1024 + r * 32 + tid]; }
+      slabX[go.b2 + tid] = sb;
+      if (gauss) {
+        const bool inside = (lsr_e >= ls_min) && (lsr_e <= ls_max);
+        slabX[go.log_std + tid] = inside ? sl * invB : 0.f;
       }
     }
-    STAMP(p, 8);
-
-    // ---- cross-wave reduction of the tile, extras, stores (as iql_bwd_kernel's (a) blocks)
-    {
-      float* myred = red + wave * 32 * T64_LD;
+    const float sA = block_sum_256(accA, rsm);
+    if (tid == 0) loss_parts[3 * 64 + lb] = sA;
+  } else if (wave == 0) {
+    float sA = accA, sB = accB, sb = accb2;
 #pragma unroll
-      for (int ta = 0; ta < 2; ++ta)
+    for (int o = 32; o > 0; o >>= 1) { sA += __shfl_xor(sA, o); sB += __shfl_xor(sB, o); sb += __shfl_xor(sb, o); }
+    if (lane == 0) {
+      slabX[go.b2] = sb;
+      if (net == IQLHIP_NET_V) loss_parts[0 * 64 + lb] = sA;
+      if (net == IQLHIP_NET_Q1) { loss_parts[1 * 64 + lb] = sA; loss_parts[2 * 64 + lb] = sB; }
+    }
+  }
+  };
+  STAMP(p, 1);
+
+  for (int rt = lb; rt < n_rt; rt += nbb) {
+    const int row0 = rt * RT_ROWS;
+    const bool first = (rt == lb);
+    // the H1 tile -> LDS
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = tid + 256 * q;
+      *(bf16x8*)(H1t + (f >> 5) * H0B_LD + 8 * (f & 31)) = T.h1q[q];
+    }
+    // ---- dy of the scalar heads / dY = w T of the policy; the per-row sums
+    if (!is_pi) {
+      if (tid < RT_ROWS) {
+        float v = 0.f, la_ = 0.f, lb_ = 0.f;
+        if (row0 + tid < B) row_finish(p, net, T.in, &v, la_, lb_);
+        dys[tid] = v;
+        accA += la_; accB += lb_; accb2 += v;
+      }
+    } else {
+      float w = 0.f;
+      if (row0 + xr < B) {
+        const float tqv = fminf(sum4(T.ph[1]), sum4(T.ph[2]));
+        const float u = tqv - sum4(T.ph[0]);
+        w = fminf(expf(beta * u), adv_max);
+      }
+      const f32x4 dy4 = T.t4 * w;
+      const bf16x4 dyb = cvt4(dy4);
+      *(bf16x4*)(dYb + xr * LB_DYLD + 4 * xc) = dyb;
+      if (row0 + xr < B) *(bf16x4*)(dyg + (unsigned)((row0 + xr) * 32 + 4 * xc)) = dyb;
+      pb2 += dy4;
+      pls += T.g4 * w;
+      if (xc == 0) accA += w * T.lrow;
+    }
+    if (first) STAMP(p, 2);
+    __syncthreads();
+    if (first) STAMP(p, 3);
+    if (first) {
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        float t8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t8[e] = (8 * g + e < D) ? w2s[jt][e] : 0.f;
+        w2A[jt] = pack8s(t8);
+      }
+    }
+    // ---- dH1 tile [32][256]: (dY . W2) masked by H1 > 0; lane: rows 16 r2 + l15, columns 64 w + 16 jt + 4 g ..
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      bf16x8 Bd = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      float dyr = 0.f;
+      if (is_pi) Bd = *(const bf16x8*)(dYb + (16 * r2 + l15) * LB_DYLD + 8 * g);
+      else dyr = dys[16 * r2 + l15];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        f32x4 pre;
+        if (is_pi) pre = MFMA_BF16(w2A[jt], Bd, ((f32x4){0.f, 0.f, 0.f, 0.f}));
+        else pre = w2q[jt] * dyr;
+        const bf16x4 hmk = *(const bf16x4*)(H1t + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g);
+        f32x4 o;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int jl = 2 * (4 * g + reg) + ta;
-          f32x4 v = (f32x4){acc[ta][0][reg], acc[ta][1][reg], acc[ta][2][reg], acc[ta][3][reg]};
-          *(f32x4*)(myred + jl * T64_LD + 4 * l15) = v;
+          const float h = (float)hmk[reg];
+          o[reg] = (h > 0.f) ? pre[reg] * dscale : 0.f;
+          dw2p[jt][reg] = fmaf(dyr, h, dw2p[jt][reg]);      // (scalar nets: dW2 = sum_r dy H1; policy: dyr = 0)
         }
-    }
-    if (extras) {
-      float* mine = exA + (wave * 4 + g) * 64 + 2 * l15;
-      *(f32x2*)mine = (f32x2){db1a[0], db1a[1]};
-      if (!is_pi) *(f32x2*)(mine + 32) = (f32x2){dw2a[0], dw2a[1]};
-      if (is_pi && do_dw2) {
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          if (dt < ndt)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-              exB[(wave * 32 + 16 * dt + 4 * g + reg) * 32 + 2 * l15 + tb_own] = acc2[dt][reg];
+        db1p[jt] += o;
+        *(bf16x4*)(dH1b + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g) = cvt4(o);
       }
     }
     __syncthreads();
+    if (first) STAMP(p, 4);
+    // ---- dH0 = dH1 . W1: the wave's 64 columns over all 256 k
     {
-      float* gw1 = slab + go.w1;
+      bf16x8 Ad[2][8];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int f = tid + 256 * q;
-        const int jl = f >> 4, i4 = f & 15;
-        f32x4 sv = *(const f32x4*)(red + jl * T64_LD + 4 * i4);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) sv += *(const f32x4*)(red + w * 32 * T64_LD + jl * T64_LD + 4 * i4);
-        *(f32x4*)(gw1 + (j0 + jl) * HID + i0 + 4 * i4) = sv;
+      for (int kb = 0; kb < 8; ++kb) {
+        Ad[0][kb] = *(const bf16x8*)(dH1b + l15 * H0B_LD + 32 * kb + 8 * g);
+        Ad[1][kb] = *(const bf16x8*)(dH1b + (16 + l15) * H0B_LD + 32 * kb + 8 * g);
       }
-    }
-    if (extras) {
-      const int e_lo = do_db1 ? 0 : 32;
-      const int e_hi = do_dw2 ? (1 + D) * 32 : 32;
-      for (int e = tid + e_lo; e < e_hi; e += 256) {
-        const int rr = e >> 5, jj = e & 31;
-        float sv;
-        if (rr == 0 || !is_pi) {
-          float wsum[4];
+      f32x4 acc[2][4];
 #pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const float* q = exA + (w * 4) * 64 + rr * 32 + jj;
-            wsum[w] = (q[0] + q[64]) + (q[128] + q[192]);
-          }
-          sv = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        } else {
-          const float* b = exB + (rr - 1) * 32 + jj;
-          sv = (b[0] + b[1024]) + (b[2048] + b[3072]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          acc[0][tb] = MFMA_BF16(Ad[0][kb], bwf[tb][kb], acc[0][tb]);
+          acc[1][tb] = MFMA_BF16(Ad[1][kb], bwf[tb][kb], acc[1][tb]);
         }
-        if (rr == 0) { if (do_db1) slab[go.b1 + j0 + jj] = sv; }
-        else if (do_dw2 && (!is_pi || (jj & 1) == tb_own)) slab[go.w2 + (rr - 1) * HID + j0 + jj] = sv;
-      }
-    }
-    if (designated) {
-      if (!is_pi) {
-        if (tid == 0) slab[go.b2] = tot_b2;
-      } else if (tid < D) {
-        slab[go.b2 + tid] = tot_b2;
-        if (gauss) {
-          const float lsr = p.log_std[tid];
-          const bool inside = (lsr >= p.hy.log_std_min) && (lsr <= p.hy.log_std_max);
-          slab[go.log_std + tid] = inside ? tot_ls * invB : 0.f;
-        }
-      }
-    }
-    STAMP(p, 9);
-    RT_STAMP(p, 14, rt_entry_);
-    RT_STAMP(p, 15, iql_realtime());
-    return;
-  }
-#undef AROW
-
-  // ===================== (b): dH1 -> dH0 -> [dW0 | db0] over a strided set of 32-row tiles =====================
-  {
-    const int lb = local_;
-    float* slabB = p.sc.slab_b + p.sc.slab_b_off[net] + (long long)lb * (HID * k0 + HID);
-    if (lb >= a.n_rt) {      // (fewer row tiles than (b) blocks: this block's slab is still summed — it must hold zeros)
-      for (int e = tid; e < HID * k0 + HID; e += 256) slabB[e] = 0.f;
-      return;
-    }
-    __bf16* dH1b = (__bf16*)smem;                        // [32][H0B_LD]
-    __bf16* dH0T = dH1b + 32 * H0B_LD;                   // [256][LB_DYLD]  masked dH0, transposed: [col][row]
-    __bf16* XT = dH0T + 256 * LB_DYLD;                   // [16 NCT][LB_DYLD] [X | 1 | 0]^T: [kc][row]
-    __bf16* dYb = XT + 16 * NCT * LB_DYLD;               // [32][LB_DYLD]  dY of the tile (policy)
-    float* dys = (float*)(dYb + 32 * LB_DYLD);           // [32] dy of the tile (scalar nets)
-    __bf16* H1t = (__bf16*)(dys + 32);                   // [32][H0B_LD] the H1 tile (mask of dH1)
-    const int nct = (k0 + 1 + 15) >> 4;
-    const int xr = tid >> 3, xc = tid & 7;
-    auto issue = [&](LbTileIn& s, int rt) {
-      const int row0 = rt * RT_ROWS;
-      // (the policy's loads are issued by every net's blocks — from valid addresses — no branch in front of the big streams)
-      if (wave == 0) row_issue(p, LBROW(row0 + (tid & 31)), s.in);
-      const unsigned prow = (unsigned)LBROW(row0 + xr);
-      const unsigned oh = prow * (unsigned)HEAD_LD;
-      s.ph[0] = *(const f32x4*)(heads + (oh + 4u)); s.ph[1] = *(const f32x4*)(heads + (oh + 8u)); s.ph[2] = *(const f32x4*)(heads + (oh + 12u));
-      s.t4 = *(const f32x4*)(a.pi_t + (prow * 32u + 4u * (unsigned)xc));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = tid + 256 * q;
-        s.h1q[q] = *(const bf16x8*)((const __bf16*)H1g + ((unsigned)LBROW(row0 + (f >> 5)) * (unsigned)HID + (unsigned)(8 * (f & 31))));
-      }
+      if (first) STAMP(p, 5);
+      // masked -> the row-major dH0 tile: a lane's 4 column tiles are 4 consecutive columns of row 16 r2 + 4 g + reg
 #pragma unroll
       for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          s.hm[r2][reg] = ld4<true>(H0g, (unsigned)LBROW(row0 + 16 * r2 + 4 * g + reg) * (unsigned)HID + (unsigned)(64 * wave + 4 * l15));
-      const unsigned xrow = prow * (unsigned)ld;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        if (q < (16 * NCT + 31) / 32) {
-          const int c = min(4 * (xc + 8 * q), (k0 - 1) & ~3);      // (c + 3 <= k0 + 2 < ld: inside the row; columns >= k0 unused)
-          s.xq[q] = *(const f32x4*)(xb + (xrow + (unsigned)c));
-        }
-      }
-    };
-    LbTileIn T;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) T.in.h[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    T.in.r = 0.f; T.in.d = 0.f;
-    if (LB_SKIP & 32) {
-      T.ph[0] = T.ph[1] = T.ph[2] = T.t4 = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) T.h1q[q] = (bf16x8){(__bf16)1.f, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) T.hm[i >> 2][i & 3] = (bf16x4){(__bf16)1.f, 0, 0, 0};
-#pragma unroll
-      for (int q = 0; q < 3; ++q) T.xq[q] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
-    } else
-    issue(T, lb);
-    // ---- the wave's operands for the whole block (requested BEHIND the first tile's inputs: the loss arithmetic and the
-    // dH1 tile run under this stream)
-    // W2: scalar nets — the lane's 16 columns j = 64 w + 16 jt + 4 g + reg; policy — A operand of dH1^T = W2^T . dY^T
-    // (m = j = 64 w + 16 jt + l15, k = dim 8 g + e)
-    f32x4 w2q[4];
-    float w2s[4][8];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      w2q[jt] = *(const f32x4*)(w2 + (unsigned)(64 * wave + 16 * jt + 4 * g));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) w2s[jt][e] = w2[(unsigned)(min(8 * g + e, D - 1) * HID + 64 * wave + 16 * jt + l15)];
-    }
-    // W1 (bf16 shadow): B operand of dH0 = dH1 . W1, k = j = 32 kb + 8 g + e, n = column 64 w + 4 l15 + tb
-    bf16x4 bw[64];
-#pragma unroll
-    for (int ks = 0; ks < 64; ++ks) {
-      if (LB_SKIP & 1) bw[ks] = (bf16x4){(__bf16)1.f, (__bf16)0.f, (__bf16)2.f, (__bf16)0.f};
-      else bw[ks] = ld4<true>(np.w1, (unsigned)((32 * (ks >> 3) + 8 * g + (ks & 7)) * HID + 64 * wave + 4 * l15));
-    }
-    bf16x8 w2A[4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      float t8[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) t8[e] = (8 * g + e < D) ? w2s[jt][e] : 0.f;
-      w2A[jt] = pack8s(t8);
-    }
-    f32x4 accW[4][NCT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NCT; ++j) accW[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    STAMP(p, 1);
-
-    for (int rt = lb; rt < a.n_rt; rt += a.nbb) {
-      const int row0 = rt * RT_ROWS;
-      const bool first = (rt == lb);
-      // [X | 1 | 0]^T as bf16: thread (row xr, kc 4 (xc + 8 q) ..)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        if (q < (16 * NCT + 31) / 32) {
-          const int c = 4 * (xc + 8 * q);
-          if (c < 16 * nct) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int kc = c + j;
-              const float xvj = (kc < k0) ? T.xq[q][j] : ((kc == k0) ? 1.f : 0.f);      // ones column -> db0
-              XT[kc * LB_DYLD + xr] = (__bf16)xvj;
-            }
-          }
-        }
-      }
-      // the H1 tile -> LDS
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = tid + 256 * q;
-        *(bf16x8*)(H1t + (f >> 5) * H0B_LD + 8 * (f & 31)) = T.h1q[q];
-      }
-      // ---- dy of the scalar heads / dY = w T of the policy
-      if (!is_pi) {
-        if (tid < RT_ROWS) {
-          float v = 0.f, la_, lb_;
-          if (row0 + tid < B) row_finish(p, net, T.in, &v, la_, lb_);
-          dys[tid] = v;
-        }
-      } else {
-        float w = 0.f;
-        if (row0 + xr < B) {
-          const float tqv = fminf(sum4(T.ph[1]), sum4(T.ph[2]));
-          const float u = tqv - sum4(T.ph[0]);
-          w = fminf(expf(p.hy.beta * u), p.hy.exp_adv_max);
-        }
-        *(bf16x4*)(dYb + xr * LB_DYLD + 4 * xc) = cvt4(T.t4 * w);
-      }
-      if (first) STAMP(p, 2);
-      __syncthreads();
-      if (first) STAMP(p, 3);
-      // ---- dH1 tile [32][256] (bf16): (dY . W2) masked by H1 > 0; lane: rows 16 r2 + l15, columns 64 w + 16 jt + 4 g ..
-#pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        bf16x8 Bd = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        float dyr = 0.f;
-        if (is_pi) Bd = *(const bf16x8*)(dYb + (16 * r2 + l15) * LB_DYLD + 8 * g);
-        else dyr = dys[16 * r2 + l15];
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-          f32x4 pre;
-          if (is_pi) pre = MFMA_BF16(w2A[jt], Bd, ((f32x4){0.f, 0.f, 0.f, 0.f}));
-          else pre = w2q[jt] * dyr;
-          const bf16x4 hmk = *(const bf16x4*)(H1t + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g);
-          f32x4 o;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) o[reg] = ((float)hmk[reg] > 0.f) ? pre[reg] * dscale : 0.f;
-          *(bf16x4*)(dH1b + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g) = cvt4(o);
-        }
-      }
-      __syncthreads();
-      if (first) STAMP(p, 4);
-      // ---- dH0 = dH1 . W1: the wave's 64 columns over all 256 k
-      {
-        bf16x8 Ad[2][8];
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-          Ad[0][kb] = *(const bf16x8*)(dH1b + l15 * H0B_LD + 32 * kb + 8 * g);
-          Ad[1][kb] = *(const bf16x8*)(dH1b + (16 + l15) * H0B_LD + 32 * kb + 8 * g);
-        }
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb)
+        for (int reg = 0; reg < 4; ++reg) {
+          bf16x4 o;
 #pragma unroll
           for (int tb = 0; tb < 4; ++tb) {
-            bf16x8 Bv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) Bv[e] = bw[8 * kb + e][tb];
-            acc[0][tb] = MFMA_BF16(Ad[0][kb], Bv, acc[0][tb]);
-            acc[1][tb] = MFMA_BF16(Ad[1][kb], Bv, acc[1][tb]);
+            const float v = ((float)T.hm[r2][reg][tb] > 0.f) ? acc[r2][tb][reg] * dscale : 0.f;      // rows >= B carry 0
+            db0p[tb] += v;
+            o[tb] = (__bf16)v;
           }
-        if (first) STAMP(p, 5);
-        // masked, transposed (bf16 [col][row]): the dW0 product's operand is then one 16-byte read
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-          for (int tb = 0; tb < 4; ++tb) {
-            bf16x4 o;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-              o[reg] = (__bf16)(((float)T.hm[r2][reg][tb] > 0.f) ? acc[r2][tb][reg] * dscale : 0.f);      // rows >= B carry 0
-            *(bf16x4*)(dH0T + (64 * wave + 4 * l15 + tb) * LB_DYLD + 16 * r2 + 4 * g) = o;
-          }
-      }
-      // the next tile's inputs: everything of this tile's has been consumed
-      if (!(LB_SKIP & 32) && rt + a.nbb < a.n_rt) issue(T, rt + a.nbb);
-      __syncthreads();
-      if (first) STAMP(p, 6);
-      // ---- [dW0 | db0][i][kc] += sum_r dH0[r][i] [X | 1][r][kc]: A = [X | 1]^T (m = kc, k = row), B = dH0T (n = i)
-      {
-        bf16x8 Ax[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) Ax[ct] = *(const bf16x8*)(XT + (16 * min(ct, nct - 1) + l15) * LB_DYLD + 8 * g);
-#pragma unroll
-        for (int itl = 0; itl < 4; ++itl) {
-          const bf16x8 Bd = *(const bf16x8*)(dH0T + (64 * wave + 16 * itl + l15) * LB_DYLD + 8 * g);
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-            if (ct < nct) accW[itl][ct] = MFMA_BF16(Ax[ct], Bd, accW[itl][ct]);
+          *(bf16x4*)(dH0b + (16 * r2 + 4 * g + reg) * H0B_LD + 64 * wave + 4 * l15) = o;
         }
-      }
-      __syncthreads();      // the next tile rewrites XT / dYb / dH1b / dH0T
-      if (first) STAMP(p, 7);
     }
-    STAMP(p, 8);
-    if (!(LB_SKIP & 4))
-    // ---- the block's slab [i][kc], db0 behind it.  A lane's 4 registers are 4 consecutive kc of one i — 16 bytes at a
-    // 4-byte-aligned address of a 268-byte row: as direct stores the 20 of them took 4-5 k cycles.  Each wave parks its 64
-    // rows (contiguous in the slab) in LDS and copies them out as aligned, fully coalesced 16-byte stores.
-    {
-      float* park = smem + wave * (64 * k0);           // (16-byte aligned: 64 k0 floats; the loop's barrier freed the tiles)
-      float* dstB = slabB + HID * k0;
+    // the next tile's inputs: everything of this tile's has been consumed
+    if (rt + nbb < n_rt) issue(T, rt + nbb);
+    __syncthreads();
+    if (first) STAMP(p, 6);
+    if (rt + nbb >= n_rt) block_sums();      // (the block's last tile)
+    // dH1 / dH0 rows -> memory (operands of dW1 = dH1^T . H0, dW0 = dH0^T . X): the tile's last instructions — a register
+    // that was a store's source is not reused before the store has completed (~4 k cycles)
 #pragma unroll
-      for (int itl = 0; itl < 4; ++itl) {
-        const int il = 16 * itl + l15;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          if (ct < nct) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const int kc = 16 * ct + 4 * g + reg;
-              if (kc < k0) park[il * k0 + kc] = accW[itl][ct][reg];
-              else if (kc == k0) dstB[64 * wave + il] = accW[itl][ct][reg];
-            }
-          }
-        }
-      }
-      float* dst = slabB + wave * (64 * k0);
-      // (all the reads first, then the stores: a read -> store loop waits for each LDS round trip in turn)
-      constexpr int NQ = (16 * (16 * NCT - 1) + 63) / 64;      // 16 k0 float4 per wave, k0 <= 16 NCT - 1
-      f32x4 cv[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) cv[q] = *(const f32x4*)(park + 4 * min(lane + 64 * q, 16 * k0 - 1));
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) if (lane + 64 * q < 16 * k0) *(f32x4*)(dst + 4 * (lane + 64 * q)) = cv[q];
+    for (int q = 0; q < 4; ++q) {
+      const int f = tid + 256 * q;
+      const int rl = f >> 5, col = 8 * (f & 31);
+      if (row0 + rl < B) *(bf16x8*)(dH1g + (unsigned)((row0 + rl) * HID + col)) = *(const bf16x8*)(dH1b + rl * H0B_LD + col);
     }
-    STAMP(p, 9);
-    RT_STAMP(p, 14, rt_entry_);
-    RT_STAMP(p, 15, iql_realtime());
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = tid + 256 * q;
+      const int rl = f >> 5, col = 8 * (f & 31);
+      if (row0 + rl < B) *(bf16x8*)(dH0g + (unsigned)((row0 + rl) * HID + col)) = *(const bf16x8*)(dH0b + rl * H0B_LD + col);
+    }
+    if (first) STAMP(p, 7);
+    // (no barrier here: the next tile's first LDS writes — H1t, dYb / dys — were last read before the barrier above, its
+    //  dH1b writes come behind its own first barrier, its dH0b writes behind its second)
   }
+  STAMP(p, 8);
+  if (lb >= n_rt) block_sums();      // (a block without row tiles still owns a slab: zeros)
+  STAMP(p, 9);
+  RT_STAMP(p, 14, rt_entry_);
+  RT_STAMP(p, 15, iql_realtime());
 #undef LBROW
+}
+
+// ---------------------------------------------------------------------------
+// Backward, row contractions: C[m][n] = sum_r P[r][m0 + m] Q[r][n0 + n] over the rows of one chunk group, for
+//   job 0..15   dW1[j][i]       P = dH1 (64 columns j0 ..), Q = H0 (64 columns i0 ..)
+//   job 16..23  dW0[i][kc]      P = dH0 (64 columns i0 ..), Q = the batch's [s | a] columns as bf16 (64 columns kc0 ..)
+//   job 24..27  policy dW2[d][j]   P = dY (32 columns), Q = H1 (64 columns j0 ..)
+// All operands are bf16 row-major matrices over the batch rows, so every job is the same code: only base pointers, row
+// strides and the output map differ (block-uniform scalars).
+// grid = 8 x ceil(28 n_cg / 2): net = x & 3, local = 2 (blockIdx >> 3) + (x >> 2) = 28 cg + job; a dW1 tile's column-tile
+// parity = (job & 1) = local & 1 = the XCD half whose update blocks read that stripe parity (iql_update_kernel).
+// 64-row stages, double-buffered in LDS as row-major [64][LB_GLD] bf16 tiles; wave (wm, wn) owns a 32 x 32 quadrant =
+// 2 x 2 MFMA tiles; both operands are read TRANSPOSED (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block,
+// lane 4 q + p passes the address of (row q, columns 4 p ..) and receives column l15 of the 4 rows;
+// tools/microbench/tr_read_check.hip).
+#define LB_GLD 72
+#define LB_NJOB 28
+__device__ __forceinline__ bf16x4 lds_tr4(const __bf16* ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)ptr);
+}
+__global__ __launch_bounds__(256) void iql_bwd_gemm_kernel(StepParams p, LbArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ps[2][64 * LB_GLD];
+  __shared__ __attribute__((aligned(16))) __bf16 Qs[2][64 * LB_GLD];
+  RT_ENTRY();
+  const int bid = blockIdx.x;
+  const int x = bid & 7;
+  const int net = x & 3;
+  const int local_ = (bid >> 3) * 2 + (x >> 2);
+  const int cg = local_ / LB_NJOB, job = local_ - cg * LB_NJOB;
+  if (cg >= a.n_cg) return;
+  const bool is_pi = (net == IQLHIP_NET_PI);
+  const int B = p.rows, MB = p.sc.max_batch;
+  const int k0 = p.net[net].k0, D = p.net[net].d;
+  const int kind = (job < 16) ? 0 : ((job < 24) ? 1 : 2);
+  const int mt = (kind == 0) ? (job >> 2) : ((kind == 1) ? ((job - 16) >> 1) : 0);
+  const int nt = (kind == 0) ? (job & 3) : ((kind == 1) ? ((job - 16) & 1) : (job - 24));
+  if (kind == 2 && !is_pi) return;
+  if (kind == 1 && 64 * nt >= k0) return;      // (no kc in this tile)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  // operands: base pointer (first column of the tile), row stride, real columns of the tile (beyond: zeros)
+  const __bf16* Pg = (kind == 0) ? a.dh1g + net * MB * HID + 64 * mt : ((kind == 1) ? a.dh0g + net * MB * HID + 64 * mt : a.dyg);
+  const int ldP = (kind == 2) ? 32 : HID;
+  const int pcols = (kind == 2) ? 32 : 64;
+  const __bf16* Qg = (kind == 0) ? (const __bf16*)p.sc.h0 + net * MB * HID + 64 * nt
+                   : ((kind == 1) ? a.xbf + 64 * nt : (const __bf16*)p.sc.h1 + net * MB * HID + 64 * nt);
+  const int ldQ = (kind == 1) ? LB_XLD : HID;
+  // output map: C[m][n] -> slab[out0 + m * ldo + n] for m < m_lim, n < n_lim
+  const long long out0 = (kind == 0) ? p.go[net].w1 + (long long)(64 * mt) * HID + 64 * nt
+                       : ((kind == 1) ? a.go_w0[net] + (long long)(64 * mt) * k0 + 64 * nt : p.go[net].w2 + 64 * nt);
+  const int ldo = (kind == 1) ? k0 : HID;
+  const int m_lim = (kind == 2) ? D : 64;
+  const int n_lim = (kind == 1) ? (k0 - 64 * nt) : 64;
+  float* slab = p.sc.slab_a + (long long)cg * p.n_params + out0;
+  PIN_P(Pg); PIN_P(Qg); PIN_P(slab); PIN_S(ldP); PIN_S(ldQ); PIN_S(pcols); PIN_S(ldo); PIN_S(m_lim); PIN_S(n_lim);
+  const int r_begin = cg * a.cpb * CHUNK_ROWS;
+  const int r_end = min(min((cg + 1) * a.cpb, a.n_chunk) * CHUNK_ROWS, (B + 63) & ~63);
+  const int n_stage = (r_end - r_begin + 63) >> 6;
+  // stage copy: thread -> rows (tid >> 3) + 32 i, 16-byte chunk tid & 7 of the tile's 128-byte rows (fully coalesced)
+  const int sr = tid >> 3, sc8 = 8 * (tid & 7);
+  const unsigned pc8 = (unsigned)min(sc8, pcols - 8);
+  const bool p_live = sc8 < pcols;
+  bf16x8 pl[2], ql[2];
+  STAMP_BASE(p, 3072 * 16);
+  STAMP(p, 0);
+#define GEMM_LOAD(s_)                                                                                   \
+  do {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
+      const unsigned row = (unsigned)min(r_begin + 64 * (s_) + sr + 32 * i, B - 1);                     \
+      pl[i] = *(const bf16x8*)(Pg + (row * (unsigned)ldP + pc8));                                       \
+      ql[i] = *(const bf16x8*)(Qg + (row * (unsigned)ldQ + (unsigned)sc8));                             \
+    }                                                                                                   \
+  } while (0)
+#define GEMM_STORE(s_, buf_)                                                                            \
+  do {                                                                                                  \
+    const bf16x8 z = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
+      const bool live = (r_begin + 64 * (s_) + sr + 32 * i) < B;      /* rows beyond the batch: zeros */ \
+      *(bf16x8*)(&Ps[buf_][(sr + 32 * i) * LB_GLD + sc8]) = (live && p_live) ? pl[i] : z;               \
+      *(bf16x8*)(&Qs[buf_][(sr + 32 * i) * LB_GLD + sc8]) = live ? ql[i] : z;                           \
+    }                                                                                                   \
+  } while (0)
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  GEMM_LOAD(0);
+  GEMM_STORE(0, 0);
+  __syncthreads();
+  STAMP(p, 1);
+  const int q4 = l15 >> 2, p4 = l15 & 3;
+  for (int s = 0; s < n_stage; ++s) {
+    const int buf = s & 1;
+    // the next stage's rows: requested now, parked in LDS behind this stage's MFMAs (the last stage re-reads its own
+    // rows: no branch around the loads)
+    GEMM_LOAD(min(s + 1, n_stage - 1));
+    // operands of the stage: k-block kb (32 rows), column tile t (16 columns): rows 32 kb + 8 g + 4 h + q4, columns 16 t + 4 p4
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 Af[2], Bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const __bf16* pa = &Ps[buf][(32 * kb + 8 * g + q4) * LB_GLD + 32 * wm + 16 * t + 4 * p4];
+        const __bf16* pb = &Qs[buf][(32 * kb + 8 * g + q4) * LB_GLD + 32 * wn + 16 * t + 4 * p4];
+        Af[t] = cat8(lds_tr4(pa), lds_tr4(pa + 4 * LB_GLD));
+        Bf[t] = cat8(lds_tr4(pb), lds_tr4(pb + 4 * LB_GLD));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MFMA_BF16(Af[i], Bf[j], acc[i][j]);
+    }
+    if (s == 0) STAMP(p, 4);
+    GEMM_STORE(min(s + 1, n_stage - 1), buf ^ 1);
+    if (s == 0) STAMP(p, 5);
+    __syncthreads();
+    if (s == 0) STAMP(p, 6);
+  }
+  STAMP(p, 2);
+  // ---- the tile -> this chunk group's slab: D[m = 4 g + reg][n = l15] of tile (i, j) = C[32 wm + 16 i + 4 g + reg][32 wn + 16 j + l15]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = 32 * wm + 16 * i + 4 * g + reg, n = 32 * wn + 16 * j + l15;
+        if (m < m_lim && n < n_lim) slab[m * ldo + n] = acc[i][j][reg];
+      }
+  STAMP(p, 3);
+  RT_STAMP(p, 14, rt_entry_);
+  RT_STAMP(p, 15, iql_realtime());
+#undef GEMM_LOAD
+#undef GEMM_STORE
 }

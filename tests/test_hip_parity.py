@@ -438,14 +438,16 @@ def test_slices_per_block_layouts_are_bit_identical(S, A, B, bf16, monkeypatch):
         # bf16 path: the multi-slice layouts share ONE backward structure (a (b) block takes the whole row tile: the waves
         # split the columns, not the k range) — they must agree bit for bit; the one-slice layout sums dH0's k range in
         # another order (four waves' partial sums), equally valid: it must agree to bf16-path accuracy
-        one = outs.pop(("0", "0"))
+        # (without the switches a bf16 batch of 600 rows takes the LARGE-BATCH kernels, iqlhip_lb_kernels.h — a third valid
+        #  bf16 evaluation of the step, held to the same accuracy; tests/test_hip_lb.py checks it against the oracle)
         ref = outs[("1", "1")]
-        for a_, b_ in zip(one[0], ref[0]):
-            for k in a_:
-                assert abs(a_[k] - b_[k]) <= 2e-3 * abs(b_[k]), (k, a_[k], b_[k])
-        for n in ref[1]:
-            for k in ref[1][n]:
-                assert np.max(np.abs(one[1][n][k] - ref[1][n][k])) <= 2.5 * 2 * 3e-4, (n, k)     # within two Adam steps' reach
+        for other in (outs.pop(("0", "0")), outs.pop((None, None))):
+            for a_, b_ in zip(other[0], ref[0]):
+                for k in a_:
+                    assert abs(a_[k] - b_[k]) <= 2e-3 * abs(b_[k]), (k, a_[k], b_[k])
+            for n in ref[1]:
+                for k in ref[1][n]:
+                    assert np.max(np.abs(other[1][n][k] - ref[1][n][k])) <= 2.5 * 2 * 3e-4, (n, k)     # within two Adam steps' reach
     else:
         ref = outs[("0", "0")]
     for key, (logs, prm, mom) in outs.items():

@@ -66,14 +66,41 @@ NAMES = ("V(s')", "V(s)", "Qt1", "Qt2", "Q1", "Q2", "PI")
 for i in (0, 1, 4, 6):
     report(f"fwd {NAMES[i]}", st[ids[inst == i]], FWD)
 report("fwd all", st[ids[inst != 7]], FWD)
-nb = 8 * ((32 * n_cg + nbb + 1) // 2)
-ids = np.arange(nb)
-local = (ids >> 3) * 2 + ((ids & 7) >> 2)
+cpb = int(os.environ.get("IQLHIP_LB_CPB", max(1, min(8, n_chunk // 4))))
+n_cg = (n_chunk + cpb - 1) // cpb
+ids = np.arange(8 * (nbb // 2))
 net = ids & 3
-LA = [(1, "W2 tile"), (2, "loads issued, dy / w"), (3, "barrier"), (4, "loss sums, dY tiles (+ barrier)"), (5, "dH1 operand"), (6, "dW1 (+dW2) MFMAs"),
-      (7, "barrier"), (8, "rest of the chunks"), (9, "reduction + stores")]
-LB = [(1, "persistent operand loads issued"), (2, "tile loads issued, X^T, dy / dY"), (3, "barrier"), (4, "dH1 tile + barrier"), (5, "dH0 reads + 64 MFMAs"),
-      (6, "mask, transposed tile + barrier"), (7, "dW0 MFMAs + barrier"), (8, "rest of the row tiles"), (9, "slab store")]
+LR = [(1, "first tile's loads + persistent operand loads issued"), (2, "H1 tile -> LDS, dy / dY (waits for the loads)"), (3, "barrier"), (4, "dH1 tile + barrier"),
+      (5, "dH1 store, dH0 reads + 64 MFMAs"), (6, "mask, dH0 tile, next tile's loads + barrier"), (7, "dH0 store"), (8, "rest of the row tiles"), (9, "block sums -> slab")]
 for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
-    report(f"bwd (b) {nm}", st[2048 + ids[(net == n) & (local < nbb)]], LB)
-    report(f"bwd (a) {nm}", st[2048 + ids[(net == n) & (local >= nbb) & (local < nbb + 32 * n_cg)]], LA)
+    report(f"bwd rows {nm}", st[2048 + ids[net == n]], LR)
+report("bwd rows all", st[2048 + ids], LR)
+ng = 8 * ((28 * n_cg + 1) // 2)
+ids = np.arange(ng)
+local = (ids >> 3) * 2 + ((ids & 7) >> 2)
+job = local % 28
+gs = st[3072 + ids]
+
+
+def greport(name, blk):
+    blk = blk[(blk[:, 0] > 0) & (blk[:, 3] > 0)]
+    if len(blk) == 0:
+        print(name, ": no blocks")
+        return
+    print(f"{name}: {len(blk)} blocks")
+    for i, j, lab in ((0, 1, "stage 0: loads -> LDS + barrier"), (1, 4, "stage 0: next loads issued, tr reads + 8 MFMAs"), (4, 5, "stage 1 -> LDS (waits for its loads)"), (5, 6, "barrier"),
+                      (6, 2, "remaining stages"), (2, 3, "tile -> slab")):
+        ok = (blk[:, i] > 0) & (blk[:, j] > 0)
+        if ok.sum():
+            dlt = blk[ok, j].astype(np.int64) - blk[ok, i].astype(np.int64)
+            print(f"   {lab:44s} median {np.median(dlt):8.0f}  p90 {np.percentile(dlt, 90):8.0f}  max {dlt.max():8d} cycles")
+    tot = blk[:, 3].astype(np.int64) - blk[:, 0].astype(np.int64)
+    t0, t1 = blk[:, 14].astype(np.int64), blk[:, 15].astype(np.int64)
+    print(f"   block total median {np.median(tot):8.0f} max {tot.max():8d} cycles;  wall: start spread {(t0.max() - t0.min()) / 100:.2f} us, "
+          f"duration median {np.median(t1 - t0) / 100:.2f} max {(t1 - t0).max() / 100:.2f} us, last end {(t1.max() - t0.min()) / 100:.2f} us after first start")
+
+
+greport("bwd gemm dW1 tiles", gs[job < 16])
+greport("bwd gemm dW0 tiles", gs[(job >= 16) & (job < 24)])
+greport("bwd gemm dW2 tiles", gs[job >= 24])
+greport("bwd gemm all", gs)
