@@ -46,7 +46,12 @@ HID = 256
 ROWS_1GPU = 1_000_000          # BASELINE.json configs[1]
 ROWS_DP = 10_000_000           # BASELINE.json configs[3]
 # rocprofv3 PMC passes of this bench command, collected by tools/profile_round.sh and committed (the newest round's file)
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_summary.json", "r02_pmc_summary.json")]
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")]
+# ... and of `bench.py --state-dim 39 --action-dim 28 --batch 1024 --precision bf16` (BASELINE configs[4]'s per-GPU share),
+# tools/profile_round.sh with BENCH_ARGS set
+PMC_SUMMARIES_C5 = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_config5.json",)]
+LB_MIN_ROWS = 512              # bf16 batches above this take the large-batch kernels (csrc/iqlhip_lb_kernels.h)
+COMPULSORY_NOTE = "compulsory HBM bytes per step = the row gather, batch x row stride (43 KB at obs 17 / act 6 / 256 rows): the state is cache-resident"
 
 
 def flops(S, A, B):
@@ -325,23 +330,40 @@ def run_rank(args, world: int) -> int:
     # (iqlhip_debug_time_kernel; events around single ~10 us launches would add their own ~3 us).
     f_fwd, f_bwd = flops(S, A, B)
     roof = None
+    lb = args.precision == "bf16" and B > LB_MIN_ROWS and S + A + 1 <= 80 and os.environ.get("IQLHIP_LB", "1") != "0"
     if rank == 0:
         batch = buf.sample(B)
         t_fwd = tr.time_kernel(batch, 0, 500)
         t_bwd = tr.time_kernel(batch, 1, 500)
         t_upd = tr.time_kernel(batch, 2, 500)
-        ach = f_bwd / (t_bwd * 1e-6) / 1e12
+        # the dominant kernel.  Small-batch kernels: the backward (one launch).  Large-batch bf16 path: the backward is two
+        # launches (row kernel + row-contraction GEMM), the forward the longest single one
+        kernel_name, t_dom, f_dom = "iql_bwd_kernel", t_bwd, f_bwd
+        kernel_us = {"iql_fwd_kernel": round(t_fwd, 3), "iql_bwd_kernel": round(t_bwd, 3), "iql_update_kernel": round(t_upd, 3)}
+        if lb:
+            t_rows = tr.time_kernel(batch, 4, 500)
+            t_gemm = tr.time_kernel(batch, 5, 500)
+            heads = 3 + A                                     # head dims of V, Q1, Q2, pi
+            f_rows = 2 * B * HID * (4 * HID + heads)          # dH0 = dH1 . W1 (x 4 nets), dH1 = dY . W2
+            f_gemm = f_bwd - f_rows                           # dW1, dW0, dW2: every contraction over the batch rows
+            kernel_us = {"iql_fwd_lb_kernel": round(t_fwd, 3), "iql_bwd_rows_kernel": round(t_rows, 3),
+                         "iql_bwd_gemm_kernel": round(t_gemm, 3), "iql_update_kernel": round(t_upd, 3)}
+            cands = [("iql_fwd_lb_kernel", t_fwd, f_fwd), ("iql_bwd_rows_kernel", t_rows, f_rows), ("iql_bwd_gemm_kernel", t_gemm, f_gemm)]
+            kernel_name, t_dom, f_dom = max(cands, key=lambda c_: c_[1])
+        ach = f_dom / (t_dom * 1e-6) / 1e12
         # HBM-side bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950
         # correction; tools/pmc_traffic.py).  Only valid for the default workload.
         traffic, mfma_util, pmc_src = None, None, None
-        if (S, A, B) == (17, 6, 256) and args.precision == "f32":
-            for path in PMC_SUMMARIES:
+        pmc_files = PMC_SUMMARIES if ((S, A, B) == (17, 6, 256) and args.precision == "f32") else (
+            PMC_SUMMARIES_C5 if ((S, A, B) == (39, 28, 1024) and lb) else [])
+        if pmc_files:
+            for path in pmc_files:
                 if not os.path.exists(path):
                     continue
                 with open(path) as fh:
                     for name, rec in json.load(fh).items():
-                        if "iql_bwd_kernel" in name:
+                        if kernel_name in name:
                             traffic = rec.get("hbm_bytes_per_launch_corrected")
                             mfma_util = rec.get("mfma_util")      # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)
                             pmc_src = os.path.relpath(path, ROOT)
@@ -350,22 +372,27 @@ def run_rank(args, world: int) -> int:
         # f32: the fp32-MFMA peak.  bf16 mode: the share of the launch's FLOPs that runs on v_mfma_f32_*_bf16 (layer 0 /
         # layer 1 forward, dW1, dH0, dW0) is priced against the bf16 peak, the rest (heads, the policy's dH1) against fp32
         peak = PEAK_F32_MFMA_TFLOPS
-        if args.precision == "bf16":
+        peak_step = peak
+        if args.precision == "bf16" and not lb:
             fp32_share = (2 * B * HID * (3 + 2 * A) * 2) / f_bwd            # dY.W2 and dW2 of the four heads
-            peak = 1.0 / (fp32_share / PEAK_F32_MFMA_TFLOPS + (1.0 - fp32_share) / PEAK_BF16_MFMA_TFLOPS)
-        roof = {"bound": "mfma", "kernel": "iql_bwd_kernel", "achieved": round(ach, 3), "peak": round(peak, 1),
+            peak = peak_step = 1.0 / (fp32_share / PEAK_F32_MFMA_TFLOPS + (1.0 - fp32_share) / PEAK_BF16_MFMA_TFLOPS)
+        elif lb:
+            # large-batch path: every product of the three kernels runs on v_mfma_f32_16x16x32_bf16 except the scalar
+            # nets' heads and their dY . W2 / dW2 (vector ALU, ~0.1 % of the FLOPs): priced against the bf16 peak
+            peak = peak_step = PEAK_BF16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": kernel_name, "achieved": round(ach, 3), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None if traffic is None else round(traffic),
+                "traffic_kind": "fabric bytes (L2 <-> memory side, Infinity-Cache hits included), not HBM bytes; " + COMPULSORY_NOTE,
                 "traffic_source": None if traffic is None else f"{pmc_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE; not measured in this run)",
                 "mfma_util_pmc": None if mfma_util is None else round(mfma_util, 4),
                 "mfma_util_source": None if mfma_util is None else pmc_src,
-                "flops_per_launch": f_bwd, "avg_launch_us": round(t_bwd, 3),
+                "flops_per_launch": f_dom, "avg_launch_us": round(t_dom, 3),
                 "avg_launch_us_source": "HIP events around 500 back-to-back launches of the kernel, in this run",
-                "kernel_us": {"iql_fwd_kernel": round(t_fwd, 3), "iql_bwd_kernel": round(t_bwd, 3),
-                              "iql_update_kernel": round(t_upd, 3)},
+                "kernel_us": kernel_us,
                 "step_flops": f_fwd + f_bwd,
                 # the same fraction for the whole step, from the TIMED region (all launches, gaps and fixed costs included)
-                "frac_step": round((f_fwd + f_bwd) * args.steps / dt / 1e12 / peak, 4)}
+                "frac_step": round((f_fwd + f_bwd) * args.steps / dt / 1e12 / peak_step, 4)}
 
     if rank != 0:
         if world > 1:
@@ -377,6 +404,14 @@ def run_rank(args, world: int) -> int:
     cfg = {"workload": f"IQL step on synthetic buffer (obs={S}, act={A}, {rows} rows), batch={B} per GPU",
            "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
            "global_steps_per_s": round(args.steps / dt, 1)}
+    # prepare_train_steps (before the --warmup steps, outside the timed region) REHEARSES every chunk graph once (64 + 16 + 4
+    # + 2 + 1 steps, parameters saved and restored) and then replays the 64-step chunk IQLHIP_PREPARE_WARM_CHUNKS times
+    # (default 16) to ramp the clocks: the timed region starts behind that many untimed steps plus --warmup
+    if not eager_dp[0]:
+        warm_chunks = 16 if world == 1 else 0
+        if os.environ.get("IQLHIP_PREPARE_WARM_CHUNKS") is not None:
+            warm_chunks = max(0, int(os.environ["IQLHIP_PREPARE_WARM_CHUNKS"])) if world == 1 else 0
+        cfg["prepare_rehearsal_steps"] = 64 + 16 + 4 + 2 + 1 + 64 * warm_chunks
     if repeats > 1:
         cfg["timed_regions_ms"] = [round(x * 1e3, 3) for x in dts]
         cfg["reported"] = f"median of {repeats} timed regions of {args.steps} steps"

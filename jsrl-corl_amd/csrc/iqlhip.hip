@@ -165,6 +165,7 @@ struct iqlhip_ctx {
   __bf16* wimg = nullptr;             // bf16 path: operand images of W1 / W0, [6][IMG_STRIDE] (iqlhip_kernels.h)
   int lb_enabled = 1;                 // diagnostic (IQLHIP_LB=0): keep the small-batch kernels at every batch size
   int lb_nbb_force = -1, lb_cpb_force = -1, lb_nbi_force = -1;   // diagnostic (IQLHIP_LB_NBB / _CPB / _NBI)
+  int lb_bwd_part = 0;                // iqlhip_debug_time_kernel only: 1 = launch the row kernel alone, 2 = the GEMM kernel alone
   size_t lds_bwd_lb = 0;
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
   hipStream_t cap_stream = nullptr;
@@ -605,7 +606,7 @@ static LbGeom lb_geom(const iqlhip_ctx* c, int rows) {
   // forward: 7 instances + the idle eighth share the chip: 32 blocks per instance, each walks ceil(n_rt / 32) row tiles
   g.nbi = std::min(even_rt, c->lb_nbi_force > 0 ? (c->lb_nbi_force + 1) & ~1 : 32);
   // backward: a net's blocks live on its two XCDs (64 CUs): (b) blocks of up to n_rt / nbb row tiles, (a) blocks of cpb chunks
-  g.nbb = std::min(std::min(even_rt, 64), c->lb_nbb_force > 0 ? (c->lb_nbb_force + 1) & ~1 : 32);
+  g.nbb = std::min(std::min(even_rt, 64), c->lb_nbb_force > 0 ? (c->lb_nbb_force + 1) & ~1 : 64);
   // GEMM blocks: 28 jobs per net and chunk group; about four chunk groups keep >= 400 blocks in flight
   g.cpb = c->lb_cpb_force > 0 ? std::min(c->lb_cpb_force, g.n_chunk) : std::max(1, std::min(8, g.n_chunk / 4));
   g.n_cg = (g.n_chunk + g.cpb - 1) / g.cpb;
@@ -626,7 +627,7 @@ static LbArgs lb_args(const iqlhip_ctx* c, int rows) {
   a.w1t = a.xbf + MB * LB_XLD;
   a.slab_x = c->slab_x;
   a.wimg = c->wimg;
-  for (int n = 0; n < 4; ++n) { a.go_w0[n] = c->L.net[n].w0; a.go_b0[n] = c->L.net[n].b0; }
+  for (int n = 0; n < 4; ++n) { a.go_w0[n] = c->L.net[n].w0; a.go_b0[n] = c->L.net[n].b0; a.go_w1n[n] = c->L.net[n].seg_begin; }
   return a;
 }
 
@@ -786,8 +787,9 @@ static void launch_bwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t 
     const LbArgs a = lb_args(c, p.rows);
     const int kq = c->dims.state_dim + c->dims.action_dim;
     (void)kq;
-    hipLaunchKernelGGL(iql_bwd_rows_kernel, dim3(8 * (a.nbb / 2)), dim3(256), c->lds_bwd_lb, st, p, a);
-    hipLaunchKernelGGL(iql_bwd_gemm_kernel, dim3(8 * ((LB_NJOB * a.n_cg + 1) / 2)), dim3(256), 0, st, p, a);
+    if (c->lb_bwd_part != 2) hipLaunchKernelGGL(iql_bwd_rows_kernel, dim3(8 * (a.nbb / 2)), dim3(256), c->lds_bwd_lb, st, p, a);
+    if (c->lb_bwd_part != 1)
+      hipLaunchKernelGGL(iql_bwd_gemm_kernel, dim3(8 * ((LB_NJOB * a.n_cg + 1 + 1) / 2)), dim3(256), 0, st, p, a);      // (+ 1: the reduction job)
     return;
   }
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;
@@ -2113,7 +2115,8 @@ extern "C" int iqlhip_debug_drain_spin(iqlhip_ctx* c, void* stream, double* spin
 // ---------------------------------------------------------------------------
 // Micro-benchmark hook: launch ONE kernel of the step `repeat` times back to back and return the
 // average time per launch (hipEvents on `stream`).  which: 0 fwd, 1 bwd, 2 update (no-op scalars:
-// step_size 0, so parameters do not move), 3 fwd+bwd+update.  Synchronous.
+// step_size 0, so parameters do not move), 3 fwd+bwd+update; large-batch bf16 path: 4 = the backward's row kernel alone,
+// 5 = its GEMM kernel alone.  Synchronous.
 extern "C" int iqlhip_debug_time_kernel(iqlhip_ctx* c, const iqlhip_batch* b, int which, int repeat, float* avg_us,
                                         void* stream) {
   if (!c || !avg_us || repeat < 1) return fail(IQLHIP_EINVAL, "bad argument");
@@ -2138,11 +2141,13 @@ extern "C" int iqlhip_debug_time_kernel(iqlhip_ctx* c, const iqlhip_batch* b, in
   refresh_shadows(c, st);
   for (int w = 0; w < 3; ++w) { launch_fwd(c, p, st); launch_bwd(c, p, st); }
   HIPCHK(hipEventRecord(e0, st));
+  c->lb_bwd_part = (which == 4) ? 1 : ((which == 5) ? 2 : 0);
   for (int i = 0; i < repeat; ++i) {
     if (which == 0 || which == 3) launch_fwd(c, p, st);
-    if (which == 1 || which == 3) launch_bwd(c, p, st);
+    if (which == 1 || which == 3 || which == 4 || which == 5) launch_bwd(c, p, st);
     if (which == 2 || which == 3) launch_upd(c, u, st);
   }
+  c->lb_bwd_part = 0;
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;

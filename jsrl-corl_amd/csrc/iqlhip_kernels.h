@@ -119,11 +119,13 @@ __device__ __forceinline__ unsigned long long iql_memtime() {
 #define STAMP(p, i)                                                                        \
   do {                                                                                     \
     const unsigned long long t_ = iql_memtime();                                           \
-    if (stamps_ && threadIdx.x == 0) stamps_[(long long)blockIdx.x * 16 + (i)] = t_;       \
+    if (stamps_ && threadIdx.x == 0 && blockIdx.x < stamps_blocks_) stamps_[(long long)blockIdx.x * 16 + (i)] = t_; \
   } while (0)
 // (stamps_ is a LOCAL copy of p.stamps: modifying the by-value kernel-argument struct itself makes the compiler
 //  copy all of it to scratch at entry — 1.1 KB per thread, ~3 us — which is what an earlier stamps build measured)
-#define STAMP_BASE(p, off) unsigned long long* const stamps_ = (p).stamps ? (p).stamps + (off) : nullptr
+// (the buffer holds 4 096 blocks x 16 stamps: a launch with more blocks than fit behind its base stamps only the first ones)
+#define STAMP_BASE(p, off) unsigned long long* const stamps_ = (p).stamps ? (p).stamps + (off) : nullptr; \
+  const unsigned stamps_blocks_ = (unsigned)((4096 * 16 - (off)) / 16)
 // the constant 100 MHz clock shared by the whole chip (s_memtime counters are local and not comparable across blocks)
 __device__ __forceinline__ unsigned long long iql_realtime() {
   unsigned long long t;
@@ -135,7 +137,7 @@ __device__ __forceinline__ unsigned long long iql_realtime() {
 #define RT_ENTRY() const unsigned long long rt_entry_ = iql_realtime()
 #define RT_STAMP(p, i, t)                                                                  \
   do {                                                                                     \
-    if (stamps_ && threadIdx.x == 0) stamps_[(long long)blockIdx.x * 16 + (i)] = (t);      \
+    if (stamps_ && threadIdx.x == 0 && blockIdx.x < stamps_blocks_) stamps_[(long long)blockIdx.x * 16 + (i)] = (t); \
   } while (0)
 #else
 #define STAMP(p, i) do {} while (0)
@@ -2155,10 +2157,16 @@ __device__ __forceinline__ void img_store4(__bf16* img, long long e, long long w
     *(bf16x4*)(img + img_w1_off(idx >> 8, idx & 255)) = r;
   } else if (e >= w0 && e < w0 + 256 * k_in) {
     const int nkb = (k_in + 31) >> 5;
+    // (row / column of element idx of the [256][k_in] matrix without an integer division: idx < 2^15, so the rounded
+    //  quotient is at most one off — fixed up by the remainder's sign)
+    const float inv_k = __builtin_amdgcn_rcpf((float)k_in);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = (int)(e - w0) + i;
-      const int unit = idx / k_in, k = idx - unit * k_in;
+      int unit = (int)((float)idx * inv_k);
+      int k = idx - unit * k_in;
+      if (k < 0) { unit -= 1; k += k_in; }
+      if (k >= k_in) { unit += 1; k -= k_in; }
       img[img_w0_off(unit, k, nkb)] = (__bf16)v[i];
     }
   }
@@ -2265,10 +2273,11 @@ __device__ __forceinline__ f32x4 slab_grad(const UpdParams& u, long long e, int 
     // [w1 | w0 | b0 | b1 | w2 | b2 | log_std]: the row contractions (w1, w0, the policy's w2) come from the chunk-group
     // slabs, every plain sum over rows (the rest) from the row blocks' slabs
     const long long w2b = nl.b0 + 2 * HID, b2b = w2b + (long long)HID * ((net == IQLHIP_NET_PI) ? u.L.net[IQLHIP_NET_PI].d_out : 1);
+    // (the row blocks' slabs have been summed into chunk-group slab 0 by iql_bwd_gemm_kernel's reduction jobs)
     const bool in_x = (e >= nl.b0) && !(net == IQLHIP_NET_PI && e >= w2b && e < b2b);
     stride = u.L.n_params;
-    base = (in_x ? u.slab_x : u.slab_a) + e;
-    n = in_x ? u.n_x : u.n_chunk;
+    base = u.slab_a + e;
+    n = in_x ? 1 : u.n_chunk;
   } else if (e >= nl.w0 && e < nl.b0 + HID) {
     stride = (long long)HID * nl.k_in + HID;
     base = u.slab_b + nl.slab_b_off + (e - nl.w0);

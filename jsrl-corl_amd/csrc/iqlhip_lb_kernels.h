@@ -33,6 +33,9 @@
 #pragma once
 #include "iqlhip_kernels.h"
 
+#ifndef LB_STAMP_TILE
+#define LB_STAMP_TILE 0
+#endif
 #ifndef LB_SKIP
 #define LB_SKIP 0           // timing experiments only (wrong results): bit 0 (b) no W1 loads, 1 (a) no H1 / H0 loads, 2 (b) no slab
 #endif                      // store, 3 (a) no T loads, 4 (a) no head loads, 5 (b) no tile loads
@@ -57,6 +60,7 @@ struct LbArgs {
   __bf16* xbf;      // [max_batch][LB_XLD] the batch's [s | a] columns as bf16 (zero beyond S + A), written by the forward's Q1 blocks
   float* slab_x;    // [64][n_params]      per row block: partial sums of b1, scalar w2, b2, log_std gradients (arena layout)
   long long go_w0[4], go_b0[4];      // arena offsets of w0 / b0 per net (the others: StepParams::go)
+  long long go_w1n[4];               // first arena element of each net's segment
   const __bf16* wimg;                // operand images of W1 / W0 (iqlhip_kernels.h), slots V, Q1, Q2, pi, target Q1, target Q2
   __bf16* w1t;                       // [4][65 536] W1 of the trained nets as the B operand of dH0 = dH1 . W1 (iql_w1t_build)
 };
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   STAMP(p, 1);
   for (; rt < n_rt; rt += nbi) {
     const int row0 = rt * RT_ROWS;
-    const bool first = (rt == ib);
+    const bool first = (rt == ib + LB_STAMP_TILE * nbi);      // (the tile whose phases the diagnostic build stamps)
     // policy: this tile's actions and dropout keep-bits (in flight under layer 0)
     // (issued by every instance, from a harmless address where unused: a branch around a load would make the compiler
     //  wait for every load in flight — in the first tile that is the whole W1 stream)
@@ -654,6 +658,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   for (int rt = lb; rt < n_rt; rt += nbb) {
     const int row0 = rt * RT_ROWS;
     const bool first = (rt == lb);
+    const bool stamped = (rt == lb + LB_STAMP_TILE * nbb);      // (the tile whose phases the diagnostic build stamps)
     // the H1 tile -> LDS
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -683,9 +688,9 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
       pls += T.g4 * w;
       if (xc == 0) accA += w * T.lrow;
     }
-    if (first) STAMP(p, 2);
+    if (stamped) STAMP(p, 2);
     __syncthreads();
-    if (first) STAMP(p, 3);
+    if (stamped) STAMP(p, 3);
     if (first) {
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
       }
     }
     __syncthreads();
-    if (first) STAMP(p, 4);
+    if (stamped) STAMP(p, 4);
     // ---- dH0 = dH1 . W1: the wave's 64 columns over all 256 k
     {
       bf16x8 Ad[2][8];
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
           acc[0][tb] = MFMA_BF16(Ad[0][kb], bwf[tb][kb], acc[0][tb]);
           acc[1][tb] = MFMA_BF16(Ad[1][kb], bwf[tb][kb], acc[1][tb]);
         }
-      if (first) STAMP(p, 5);
+      if (stamped) STAMP(p, 5);
       // masked -> the row-major dH0 tile: a lane's 4 column tiles are 4 consecutive columns of row 16 r2 + 4 g + reg
 #pragma unroll
       for (int r2 = 0; r2 < 2; ++r2)
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
     // the next tile's inputs: everything of this tile's has been consumed
     if (rt + nbb < n_rt) issue(T, rt + nbb);
     __syncthreads();
-    if (first) STAMP(p, 6);
+    if (stamped) STAMP(p, 6);
     if (rt + nbb >= n_rt) block_sums();      // (the block's last tile)
     // dH1 / dH0 rows -> memory (operands of dW1 = dH1^T . H0, dW0 = dH0^T . X): the tile's last instructions — a register
     // that was a store's source is not reused before the store has completed (~4 k cycles)
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
       const int rl = f >> 5, col = 8 * (f & 31);
       if (row0 + rl < B) *(bf16x8*)(dH0g + (unsigned)((row0 + rl) * HID + col)) = *(const bf16x8*)(dH0b + rl * H0B_LD + col);
     }
-    if (first) STAMP(p, 7);
+    if (stamped) STAMP(p, 7);
     // (no barrier here: the next tile's first LDS writes — H1t, dYb / dys — were last read before the barrier above, its
     //  dH1b writes come behind its own first barrier, its dH0b writes behind its second)
   }
@@ -802,7 +807,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
 // lane 4 q + p passes the address of (row q, columns 4 p ..) and receives column l15 of the 4 rows;
 // tools/microbench/tr_read_check.hip).
 #define LB_GLD 72
-#define LB_NJOB 28
+#define LB_NJOB 28          // per net and chunk group; job 28 exists once per net (chunk group 0 only): see below
 __device__ __forceinline__ bf16x4 lds_tr4(const __bf16* ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)ptr);
 }
@@ -815,7 +820,31 @@ __global__ __launch_bounds__(256) void iql_bwd_gemm_kernel(StepParams p, LbArgs 
   const int net = x & 3;
   const int local_ = (bid >> 3) * 2 + (x >> 2);
   const int cg = local_ / LB_NJOB, job = local_ - cg * LB_NJOB;
-  if (cg >= a.n_cg) return;
+  if (cg >= a.n_cg) {
+    // ---- one extra block per net (local = 28 n_cg): the row blocks' slabs of plain row sums (b0, b1, the scalar nets' w2,
+    // b2, log_std — ~1 300 floats per net in nbb slabs) summed into chunk-group slab 0, so that the update kernel reads
+    // them like everything else instead of walking up to 64 slabs on its own critical path
+    if (local_ != LB_NJOB * a.n_cg) return;
+    const long long x0 = a.go_b0[net];                                   // [b0 | b1 | w2 | b2 | log_std] is one run of the arena
+    const long long x1 = (net < 3) ? a.go_w1n[net + 1] : p.n_params;     // ... up to the next net's segment
+    const long long pw2 = p.go[net].w2, pb2 = p.go[net].b2;
+    const bool is_pi_ = (net == IQLHIP_NET_PI);
+    const int nbb = a.nbb;
+    float* dst = p.sc.slab_a;
+    for (long long e = x0 + 4 * (long long)threadIdx.x; e < x1; e += 4 * 256) {
+      if (is_pi_ && e >= pw2 && e < pb2) continue;                        // (the policy's w2 is a row contraction: jobs 24..27)
+      f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int r0 = 0; r0 < nbb; r0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(a.slab_x + (long long)min(r0 + j, nbb - 1) * p.n_params + e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (r0 + j < nbb) sum += v[j];
+      }
+      *(f32x4*)(dst + e) = sum;
+    }
+    return;
+  }
   const bool is_pi = (net == IQLHIP_NET_PI);
   const int B = p.rows, MB = p.sc.max_batch;
   const int k0 = p.net[net].k0, D = p.net[net].d;

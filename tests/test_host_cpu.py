@@ -397,3 +397,17 @@ def test_bench_rank_supervisor_stops_everything_on_the_first_failure_and_on_time
     assert time.monotonic() - t0 < 10.0 and all(p.poll() is not None for p in procs)
     ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
     assert bench.wait_ranks(ok, timeout_s=30.0) == 0
+
+
+def test_asm_prefetch_guard_checks_the_four_one_slice_backward_instantiations():
+    """__graft_entry__.check_asm_prefetch disassembles the built code object: the un-waited inline-asm kernel-argument
+    prefetch of the one-slice backward instantiations (csrc/iqlhip_kernels.h) must have its eight destination SGPRs
+    untouched on every path up to an s_waitcnt lgkmcnt(0).  It fails closed — exactly four instantiations are expected
+    (a changed template signature or a missing pattern raises instead of passing silently)."""
+    import __graft_entry__ as g
+    g.build()
+    rep = g.check_asm_prefetch()
+    assert len(rep) == 4
+    for name, r in rep.items():
+        assert "ELb0EEv" in name and len(r["prefetch_dest_sgprs"]) == 8
+        assert r["retiring_waits"] >= 1 and r["instructions_checked"] > 100

@@ -23,7 +23,9 @@ tr = iql.ImplicitQLearning(1.0, actor, torch.optim.Adam(actor.parameters(), lr=3
 d = synth.synth_transitions(B, S, A, seed=1)
 tb = to_torch_batch({"s": d["observations"], "a": d["actions"], "r": d["rewards"], "ns": d["next_observations"],
                      "d": d["terminals"]})
-tr.train(tb)
+d0 = synth.synth_transitions(256, S, A, seed=2)      # (the context is created by a small fp32 step: the diagnostic build's
+tr.train(to_torch_batch({"s": d0["observations"], "a": d0["actions"], "r": d0["rewards"], "ns": d0["next_observations"],
+                         "d": d0["terminals"]}))      #  stamp buffer is sized for the launches this tool looks at)
 tr.set_precision("bf16")
 for it in range(int(os.environ.get("ITERS", 300))):
     tr.train(tb)
