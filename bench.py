@@ -202,8 +202,20 @@ def run_rank(args, world: int) -> int:
     # ---- synthetic HBM-resident buffer + nets (seed 0; every rank holds the same replicated buffer)
     # (rows are generated on the device, identically on every rank: Philox fill kernel with synth.py's distributions —
     #  at 10 M rows the host generator cost every rank ~30 s of numpy and a 1.7 GB upload)
+    # wall-clock of the start-up phases (rank 0's view; every rank does the same work): the driver's 8-GPU run has a 600 s
+    # limit, and none of this is in the timed region
+    phases = {}
+    t_ph = [time.perf_counter()]
+
+    def phase(name):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        phases[name] = round(now - t_ph[0], 3)
+        t_ph[0] = now
+
     buf = iql.ReplayBuffer(S, A, rows, dev)
     buf.fill_synthetic(rows, seed=0)
+    phase("buffer_fill_s")
     torch.manual_seed(0)
     qf, vf, actor = iql.TwinQ(S, A).to(dev), iql.ValueFunction(S).to(dev), iql.GaussianPolicy(S, A, 1.0).to(dev)
     tr = iql.ImplicitQLearning(
@@ -214,6 +226,7 @@ def run_rank(args, world: int) -> int:
     tr.reserve_batch(B)
     if args.precision == "bf16":
         tr.set_precision("bf16")
+    phase("trainer_setup_s")
 
     def fence():
         torch.cuda.synchronize()
@@ -259,15 +272,18 @@ def run_rank(args, world: int) -> int:
     if world > 1:
         want = args.exchange
         tr.enable_data_parallel(exchange={"auto": "both", "rccl": "rccl", "p2p": "p2p"}[want])
+        phase("exchange_attach_s")
         modes = ["p2p", "rccl"] if want == "auto" else [want]
         if want == "auto":
             for m, attr in (("p2p", "_p2p_error"), ("rccl", "_rccl_error")):
                 if getattr(tr, attr, None):              # that exchange could not be attached on some rank
                     modes.remove(m)
                     probe[m] = {"unavailable": getattr(tr, attr)}
+        attached = list(modes)
         for m in modes:
             tr.select_exchange(m)
             tr.prepare_train_steps(buf, B)
+            phase(f"prepare_{m}_s")
 
         def probe_mode(m, n):
             """n steps on exchange m: rate, and whether it left the replicas bit-identical with no wait timed out.  A
@@ -310,8 +326,10 @@ def run_rank(args, world: int) -> int:
             tr.select_exchange("torch")
         else:
             tr.select_exchange(exchange)
+        phase("exchange_probe_s")
     else:
         tr.prepare_train_steps(buf, B)       # capture + instantiate + upload the chunk graph: never in the timed region
+        phase("prepare_s")
 
     if warm > 0:
         run(warm)
@@ -412,6 +430,7 @@ def run_rank(args, world: int) -> int:
         if os.environ.get("IQLHIP_PREPARE_WARM_CHUNKS") is not None:
             warm_chunks = max(0, int(os.environ["IQLHIP_PREPARE_WARM_CHUNKS"])) if world == 1 else 0
         cfg["prepare_rehearsal_steps"] = 64 + 16 + 4 + 2 + 1 + 64 * warm_chunks
+    cfg["startup_phases_s"] = phases       # untimed start-up work, wall-clock on rank 0 (import and process launch not included)
     if repeats > 1:
         cfg["timed_regions_ms"] = [round(x * 1e3, 3) for x in dts]
         cfg["reported"] = f"median of {repeats} timed regions of {args.steps} steps"
@@ -420,8 +439,11 @@ def run_rank(args, world: int) -> int:
         cfg["exchange_why"] = why
         if probe:
             cfg["exchange_probe"] = probe
-        cfg["multi_gpu_note"] = ("ranks on distinct GPUs" if torch.cuda.device_count() >= world
-                                 else f"REHEARSAL: {world} ranks share {torch.cuda.device_count()} GPU(s) — not a scaling measurement")
+        refused = {m: v["unavailable"] for m, v in probe.items() if isinstance(v, dict) and "unavailable" in v}
+        cfg["multi_gpu_note"] = (("ranks on distinct GPUs" if torch.cuda.device_count() >= world
+                                  else f"REHEARSAL: {world} ranks share {torch.cuda.device_count()} GPU(s) — not a scaling measurement")
+                                 + f"; exchanges attached: {attached if want == 'auto' else [want]}; refused: {refused if refused else 'none'}"
+                                 + f"; timed region ran on: {exchange}")
     out = {
         "metric": f"IQL gradient-steps/sec at batch={B} (D4RL obs/act dims)",      # BASELINE.json's metric at the default B = 256
         "value": round(value, 1),

@@ -379,8 +379,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   }
   {
     // large-batch backward, row blocks: [dH1 tile | H1 tile | dH0 tile | dY | dy] (iql_bwd_rows_kernel)
-    c->lds_bwd_lb = (size_t)(3 * 32 * H0B_LD + 32 * LB_DYLD) * 2 + 32 * 4 +
-                    (size_t)(2 * 16 * 260 + 2 * 32 * 32 + 4 * 256 + 16) * 4;      // (+ the block sums' partials)
+    c->lds_bwd_lb = (size_t)(3 * 32 * H0B_LD + 32 * LB_DYLD) * 2 + 32 * 4 + (size_t)(2 * 4 * 32 + 16) * 4;      // (+ the block sums' partials)
     HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd_lb));
   }
   return IQLHIP_OK;
@@ -1181,15 +1180,17 @@ extern "C" int iqlhip_get_timing(iqlhip_ctx* c, float out_us[4]) {
 // synchronise was measured at 12-17 us of host time AFTER the GPU had finished, profiles/r03_sync_cost.txt); bounded —
 // after 2 s the stream is synchronised the ordinary way, so a lost store cannot hang the caller.
 static int wait_done(iqlhip_ctx* c, unsigned long long val, hipStream_t st) {
-  const volatile unsigned long long* f = c->done_pin;
-  if (*f == val) return IQLHIP_OK;
+  // (acquire loads: the callers read the pinned loss words right behind this — those loads must not move in front of
+  //  the flag's)
+  const unsigned long long* f = c->done_pin;
+  if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == val) return IQLHIP_OK;
   const double t0 = now_us();
   for (;;) {
-    for (int i = 0; i < 256; ++i) if (*f == val) return IQLHIP_OK;
+    for (int i = 0; i < 256; ++i) if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == val) return IQLHIP_OK;
     if (now_us() - t0 > 2e6) break;
   }
   HIPCHK(hipStreamSynchronize(st));
-  if (*f != val) return fail(IQLHIP_EHIP, "the step's completion word was not written");
+  if (__atomic_load_n(f, __ATOMIC_ACQUIRE) != val) return fail(IQLHIP_EHIP, "the step's completion word was not written");
   return IQLHIP_OK;
 }
 
@@ -2043,7 +2044,7 @@ extern "C" int iqlhip_rows_sample_packed(const float* rows_dev, int64_t ld, int6
   sg.want[k] = ++sg.seq;
   sg.stream[k] = (hipStream_t)stream;
   hipLaunchKernelGGL(iql_gather_hostidx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows_dev,
-                     (long long)ld, (const long long*)sg.host[k], out_rows_dev, (int)n, sg.arrivals, sg.ack + k, sg.want[k]);
+                     (long long)ld, (const long long*)sg.host[k], out_rows_dev, (int)n, (long long)n_rows, sg.arrivals, sg.ack + k, sg.want[k]);
   HIPCHK(hipGetLastError());
   return IQLHIP_OK;
 }

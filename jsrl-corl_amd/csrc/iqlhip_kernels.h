@@ -2390,8 +2390,10 @@ __global__ __launch_bounds__(256) void iql_gather_kernel(const float* rows, long
 // The same with the indices read straight from a pinned, host-mapped slot (ReplayBuffer.sample: no H2D copy, no
 // event): every block first parks the indices of ITS rows in LDS, then the block that finishes last acknowledges the
 // slot in a host-mapped word — the host reuses the slot once it sees the call's number there (cf. iql_call_setup_kernel).
+// (n_rows: an index outside [0, n_rows) — the host checks them before the launch; this only guards a reused pinned slot —
+//  is never dereferenced: its row is filled with NaN, as in gather_rows_flat)
 __global__ __launch_bounds__(256) void iql_gather_hostidx_kernel(const float* rows, long long ld, const long long* idx_host,
-                                                                 float* xb, int n, unsigned* arrivals,
+                                                                 float* xb, int n, long long n_rows, unsigned* arrivals,
                                                                  unsigned long long* ack, unsigned long long ack_val) {
   __shared__ long long s_idx[260];
   const int q = (int)(ld >> 2);
@@ -2410,7 +2412,15 @@ __global__ __launch_bounds__(256) void iql_gather_hostidx_kernel(const float* ro
   const int e = e0 + (int)threadIdx.x;
   if (e < n * q) {
     const int r = e / q, c4 = e - r * q;
-    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = *(const f32x4*)(rows + s_idx[r - r_first] * ld + 4 * c4);
+    const long long i = s_idx[r - r_first];
+    f32x4 v;
+    if (i < 0 || i >= n_rows) {
+      const float nanv = __builtin_nanf("");
+      v = (f32x4){nanv, nanv, nanv, nanv};
+    } else {
+      v = *(const f32x4*)(rows + i * ld + 4 * c4);
+    }
+    *(f32x4*)(xb + (long long)r * ld + 4 * c4) = v;
   }
 }
 

@@ -65,6 +65,15 @@ struct LbArgs {
   __bf16* w1t;                       // [4][65 536] W1 of the trained nets as the B operand of dH0 = dH1 . W1 (iql_w1t_build)
 };
 
+// Sum of v over the 16 lanes of a row (lanes 16 g .. 16 g + 15), left in every lane of the row: four DPP row rotations
+// (row_ror:8 / 4 / 2 / 1) — vector-ALU instructions, no LDS round trip (__shfl_xor goes through ds_bpermute).
+__device__ __forceinline__ float row16_sum(float v) {
+#define ROR_ADD(n_) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n_), 0xF, 0xF, false))
+  ROR_ADD(8); ROR_ADD(4); ROR_ADD(2); ROR_ADD(1);
+#undef ROR_ADD
+  return v;
+}
+
 __device__ __forceinline__ bf16x4 cvt4(const f32x4 v) {
   bf16x4 r;
 #pragma unroll
@@ -607,41 +616,52 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   // behind it, the first registers it touches were the copy-out stores' sources, and the block waited ~4 k cycles for
   // those stores to complete before it even started — and then once more for its own stores at the end of the kernel.
   auto block_sums = [&]() {
-  float* part1 = (float*)(dys + 32);   // [16][260] db1 partials by the lanes' l15 (260: the 16 rows a write touches spread over the banks)
-  float* part2 = part1 + 16 * 260;     // [16][260] scalar dW2 partials
-  float* pip = part2 + 16 * 260;       // [2][32][32] policy db2 / dlog_std partials by xr
-  float* part0 = pip + 2 * 32 * 32;    // [4][256] db0 partials by the lanes' g
-  float* rsm = part0 + 4 * 256;        // [16]
+  float* pip = (float*)(dys + 32);     // [2][4 waves][32] policy db2 / dlog_std partials
+  float* rsm = pip + 2 * 4 * 32;       // [16]
+  // column sums over the lanes that hold the same columns, in registers: db1 / scalar dW2 — the 16 lanes l15 of a row
+  // (four rotations within the row, DPP: every lane ends up with the row's sum); db0 — the four rows g (two shuffles)
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    *(f32x4*)(part1 + l15 * 260 + 64 * wave + 16 * jt + 4 * g) = db1p[jt];
-    *(f32x4*)(part2 + l15 * 260 + 64 * wave + 16 * jt + 4 * g) = dw2p[jt];
-  }
-  *(f32x4*)(part0 + g * 256 + 64 * wave + 4 * l15) = db0p;
-  *(f32x4*)(pip + xr * 32 + 4 * xc) = pb2;
-  *(f32x4*)(pip + 1024 + xr * 32 + 4 * xc) = pls;
-  __syncthreads();
-  {
-    float s1 = 0.f, s2 = 0.f;
+  for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-    for (int l = 0; l < 16; ++l) { s1 += part1[l * 260 + tid]; s2 += part2[l * 260 + tid]; }
-    slabX[go.b1 + tid] = s1;
-    if (!is_pi) slabX[go.w2 + tid] = s2;
-    slabX[go_b0 + tid] = (part0[tid] + part0[256 + tid]) + (part0[512 + tid] + part0[768 + tid]);
+    for (int reg = 0; reg < 4; ++reg) {
+      db1p[jt][reg] = row16_sum(db1p[jt][reg]);
+      dw2p[jt][reg] = row16_sum(dw2p[jt][reg]);
+    }
+#pragma unroll
+  for (int tb = 0; tb < 4; ++tb) {
+    db0p[tb] += __shfl_xor(db0p[tb], 16);
+    db0p[tb] += __shfl_xor(db0p[tb], 32);
   }
+  if (l15 == 0) {
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      *(f32x4*)(slabX + go.b1 + 64 * wave + 16 * jt + 4 * g) = db1p[jt];
+      if (!is_pi) *(f32x4*)(slabX + go.w2 + 64 * wave + 16 * jt + 4 * g) = dw2p[jt];
+    }
+  }
+  if (g == 0) *(f32x4*)(slabX + go_b0 + 64 * wave + 4 * l15) = db0p;
   if (is_pi) {
+    // dims 4 xc .. of the thread, over the wave's 8 row groups (lanes 8 apart), then over the four waves through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { pb2[j] += __shfl_xor(pb2[j], o); pls[j] += __shfl_xor(pls[j], o); }
+    }
+    if (lane < 8) {
+      *(f32x4*)(pip + wave * 32 + 4 * lane) = pb2;
+      *(f32x4*)(pip + 128 + wave * 32 + 4 * lane) = pls;
+    }
+    const float sA = block_sum_256(accA, rsm);      // (its barriers also publish pip)
+    if (tid == 0) loss_parts[3 * 64 + lb] = sA;
     if (tid < D) {
-      float sb = 0.f, sl = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < 32; ++r) { sb += pip[r * 32 + tid]; sl += pip[1024 + r * 32 + tid]; }
+      const float sb = (pip[tid] + pip[32 + tid]) + (pip[64 + tid] + pip[96 + tid]);
+      const float sl = (pip[128 + tid] + pip[160 + tid]) + (pip[192 + tid] + pip[224 + tid]);
       slabX[go.b2 + tid] = sb;
       if (gauss) {
         const bool inside = (lsr_e >= ls_min) && (lsr_e <= ls_max);
         slabX[go.log_std + tid] = inside ? sl * invB : 0.f;
       }
     }
-    const float sA = block_sum_256(accA, rsm);
-    if (tid == 0) loss_parts[3 * 64 + lb] = sA;
   } else if (wave == 0) {
     float sA = accA, sB = accB, sb = accb2;
 #pragma unroll
@@ -878,24 +898,43 @@ __global__ __launch_bounds__(256) void iql_bwd_gemm_kernel(StepParams p, LbArgs 
   const int sr = tid >> 3, sc8 = 8 * (tid & 7);
   const unsigned pc8 = (unsigned)min(sc8, pcols - 8);
   const bool p_live = sc8 < pcols;
-  bf16x8 pl[2], ql[2];
+  // Two register sets: the rows of stage s + 2 are requested while stage s is multiplied and stage s + 1 (requested one
+  // iteration earlier) is parked in LDS — with one stage of look-ahead the ~700 cycles of a stage's arithmetic did not
+  // cover the loads' latency (stamps: ~900 cycles of every stage waiting for them).
+  bf16x8 plA[2], qlA[2], plB[2], qlB[2];
   STAMP_BASE(p, 3072 * 16);
   STAMP(p, 0);
-#define GEMM_LOAD(s_)                                                                                   \
+#define GEMM_LOAD(pl_, ql_, s_)                                                                         \
   do {                                                                                                  \
+    const int s__ = min((s_), n_stage - 1);      /* (beyond the last stage: re-read it, never used — no branch) */ \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
-      const unsigned row = (unsigned)min(r_begin + 64 * (s_) + sr + 32 * i, B - 1);                     \
-      pl[i] = *(const bf16x8*)(Pg + (row * (unsigned)ldP + pc8));                                       \
-      ql[i] = *(const bf16x8*)(Qg + (row * (unsigned)ldQ + (unsigned)sc8));                             \
+      const unsigned row = (unsigned)min(r_begin + 64 * s__ + sr + 32 * i, B - 1);                      \
+      pl_[i] = *(const bf16x8*)(Pg + (row * (unsigned)ldP + pc8));                                      \
+      ql_[i] = *(const bf16x8*)(Qg + (row * (unsigned)ldQ + (unsigned)sc8));                            \
     }                                                                                                   \
   } while (0)
-#define GEMM_STORE(s_, buf_)                                                                            \
+#define GEMM_STORE(pl_, ql_, s_, buf_)                                                                  \
   do {                                                                                                  \
     const bf16x8 z = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};                                                  \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
       const bool live = (r_begin + 64 * (s_) + sr + 32 * i) < B;      /* rows beyond the batch: zeros */ \
-      *(bf16x8*)(&Ps[buf_][(sr + 32 * i) * LB_GLD + sc8]) = (live && p_live) ? pl[i] : z;               \
-      *(bf16x8*)(&Qs[buf_][(sr + 32 * i) * LB_GLD + sc8]) = live ? ql[i] : z;                           \
+      *(bf16x8*)(&Ps[buf_][(sr + 32 * i) * LB_GLD + sc8]) = (live && p_live) ? pl_[i] : z;              \
+      *(bf16x8*)(&Qs[buf_][(sr + 32 * i) * LB_GLD + sc8]) = live ? ql_[i] : z;                          \
+    }                                                                                                   \
+  } while (0)
+  // one stage from LDS buffer buf_: k-block kb (32 rows), column tile t (16 columns): rows 32 kb + 8 g + 4 h + q4, columns 16 t + 4 p4
+#define GEMM_STAGE(buf_)                                                                                \
+  do {                                                                                                  \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                  \
+      bf16x8 Af[2], Bf[2];                                                                              \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                   \
+        const __bf16* pa = &Ps[buf_][(32 * kb + 8 * g + q4) * LB_GLD + 32 * wm + 16 * t + 4 * p4];      \
+        const __bf16* pb = &Qs[buf_][(32 * kb + 8 * g + q4) * LB_GLD + 32 * wn + 16 * t + 4 * p4];      \
+        Af[t] = cat8(lds_tr4(pa), lds_tr4(pa + 4 * LB_GLD));                                            \
+        Bf[t] = cat8(lds_tr4(pb), lds_tr4(pb + 4 * LB_GLD));                                            \
+      }                                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = MFMA_BF16(Af[i], Bf[j], acc[i][j]);   \
     }                                                                                                   \
   } while (0)
   f32x4 acc[2][2];
@@ -903,37 +942,26 @@ __global__ __launch_bounds__(256) void iql_bwd_gemm_kernel(StepParams p, LbArgs 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  GEMM_LOAD(0);
-  GEMM_STORE(0, 0);
+  const int q4 = l15 >> 2, p4 = l15 & 3;
+  GEMM_LOAD(plA, qlA, 0);
+  GEMM_LOAD(plB, qlB, 1);
+  GEMM_STORE(plA, qlA, 0, 0);
   __syncthreads();
   STAMP(p, 1);
-  const int q4 = l15 >> 2, p4 = l15 & 3;
-  for (int s = 0; s < n_stage; ++s) {
-    const int buf = s & 1;
-    // the next stage's rows: requested now, parked in LDS behind this stage's MFMAs (the last stage re-reads its own
-    // rows: no branch around the loads)
-    GEMM_LOAD(min(s + 1, n_stage - 1));
-    // operands of the stage: k-block kb (32 rows), column tile t (16 columns): rows 32 kb + 8 g + 4 h + q4, columns 16 t + 4 p4
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      bf16x8 Af[2], Bf[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const __bf16* pa = &Ps[buf][(32 * kb + 8 * g + q4) * LB_GLD + 32 * wm + 16 * t + 4 * p4];
-        const __bf16* pb = &Qs[buf][(32 * kb + 8 * g + q4) * LB_GLD + 32 * wn + 16 * t + 4 * p4];
-        Af[t] = cat8(lds_tr4(pa), lds_tr4(pa + 4 * LB_GLD));
-        Bf[t] = cat8(lds_tr4(pb), lds_tr4(pb + 4 * LB_GLD));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = MFMA_BF16(Af[i], Bf[j], acc[i][j]);
-    }
+  // (stages come in pairs: even stages live in LDS buffer 0 / register set A, odd ones in buffer 1 / set B)
+  for (int s = 0; s < n_stage; s += 2) {
+    GEMM_LOAD(plA, qlA, s + 2);
+    GEMM_STAGE(0);
     if (s == 0) STAMP(p, 4);
-    GEMM_STORE(min(s + 1, n_stage - 1), buf ^ 1);
+    GEMM_STORE(plB, qlB, min(s + 1, n_stage - 1), 1);
     if (s == 0) STAMP(p, 5);
     __syncthreads();
     if (s == 0) STAMP(p, 6);
+    if (s + 1 >= n_stage) break;
+    GEMM_LOAD(plB, qlB, s + 3);
+    GEMM_STAGE(1);
+    GEMM_STORE(plA, qlA, min(s + 2, n_stage - 1), 0);
+    __syncthreads();
   }
   STAMP(p, 2);
   // ---- the tile -> this chunk group's slab: D[m = 4 g + reg][n = l15] of tile (i, j) = C[32 wm + 16 i + 4 g + reg][32 wn + 16 j + l15]
@@ -951,4 +979,5 @@ __global__ __launch_bounds__(256) void iql_bwd_gemm_kernel(StepParams p, LbArgs 
   RT_STAMP(p, 15, iql_realtime());
 #undef GEMM_LOAD
 #undef GEMM_STORE
+#undef GEMM_STAGE
 }

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Dict, List
 
+import os
+
 import numpy as np
 import torch
 
@@ -23,6 +25,8 @@ TensorBatch = List[torch.Tensor]
 
 # (data_ptr of the observations view, rows, S, A, row stride, device) of the block the last GPU sample() produced
 _last_block = None
+# sample(): packed blocks (and their five views) recycled per batch size; 0 = a fresh block per call
+SAMPLE_RING = max(0, int(os.environ.get("IQLHIP_SAMPLE_RING", "8")))
 
 
 def _is_gpu(device) -> bool:
@@ -51,6 +55,7 @@ class ReplayBuffer:
         self._rows_ptr = self._rows.data_ptr()
         pad = self._ld - w
         self._split_sizes = [state_dim, action_dim, state_dim, 1, 1] + ([pad] if pad else [])
+        self._sample_ring = {}      # batch size -> [[(block, five views, block address)] * SAMPLE_RING, next slot]
         # bumped by every method that writes rows: ImplicitQLearning.train_steps may start a call on rows its previous
         # call staged ahead only while the buffer's contents are what they were then
         self._writes = 0
@@ -259,21 +264,37 @@ class ReplayBuffer:
         if indices.dtype != np.int64:
             indices = indices.astype(np.int64)
         dev = self._rows.device
-        block = torch.empty((batch_size, self._ld), dtype=torch.float32, device=dev)
+        # The packed block and its five views come from a ring of SAMPLE_RING pre-built ones per batch size (allocating
+        # the block and splitting it cost ~8 us of host time per call — a third of sample()).  A returned batch therefore
+        # stays untouched for the next SAMPLE_RING - 1 calls of sample() with that batch size; the reference's loops use
+        # a batch in the train() call that follows and drop it (algorithms/finetune/iql.py:771-773, jsrl_w_iql.py:544-548).
+        # IQLHIP_SAMPLE_RING=0 restores a fresh block per call.
+        ring = self._sample_ring.get(batch_size) if SAMPLE_RING > 0 else None
+        if ring is None:
+            n_slots = max(SAMPLE_RING, 1)
+            slots = []
+            for _ in range(n_slots):
+                block = torch.empty((batch_size, self._ld), dtype=torch.float32, device=dev)
+                # five views of the block in ONE split (s, a, s', r, d[, pad]) -> the reference's order s, a, r, s', d
+                parts = block.split(self._split_sizes, dim=1)
+                slots.append((block, (parts[0], parts[1], parts[3], parts[2], parts[4]), block.data_ptr()))
+            ring = [slots, 0]
+            if SAMPLE_RING > 0:
+                self._sample_ring[batch_size] = ring
+        slots, k = ring
+        ring[1] = (k + 1) % len(slots)
+        block, views, block_ptr = slots[k]
         if torch.cuda.current_device() == dev.index:
             hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows_ptr, self._ld, self._buffer_size,
-                                                        indices.ctypes.data, batch_size, block.data_ptr(), self._stream()))
+                                                        indices.ctypes.data, batch_size, block_ptr, self._stream()))
         else:
             with torch.cuda.device(dev):
                 hb.check(hb.lib().iqlhip_rows_sample_packed(self._rows_ptr, self._ld, self._buffer_size,
-                                                            indices.ctypes.data, batch_size, block.data_ptr(),
-                                                            self._stream()))
-        # five views of the block in ONE split (s, a, s', r, d[, pad]) -> the reference's order s, a, r, s', d
-        parts = block.split(self._split_sizes, dim=1)
-        batch = [parts[0], parts[1], parts[3], parts[2], parts[4]]
+                                                            indices.ctypes.data, batch_size, block_ptr, self._stream()))
+        batch = list(views)
         # ImplicitQLearning.train recognises a batch that IS such a freshly gathered block (it is consumed in place)
         global _last_block
-        _last_block = (batch[0].data_ptr(), batch_size, self._state_dim, self._action_dim, self._ld, dev)
+        _last_block = (block_ptr, batch_size, self._state_dim, self._action_dim, self._ld, dev)
         return batch
 
     def add_transition(self, state: np.ndarray, action: np.ndarray, reward: float, next_state: np.ndarray,

@@ -20,6 +20,8 @@ import ctypes as C
 import warnings
 from typing import Any, Dict, List, Optional, Tuple
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -706,7 +708,9 @@ class ImplicitQLearning:
             tab = self._scalar_table(k, inv_batch)
             # IQLHIP_TS_CONTINUE: nothing has written this buffer's rows since our previous call on it (the buffer
             # counts its writes); the library itself checks that this call starts where that one's index stream ended
-            tok = (replay_buffer, replay_buffer._writes)
+            # (a weak reference: the token must not keep a multi-GB buffer alive; the tensor's version counter sees in-place
+            #  writes through the reference-named views _states / _rewards / ..., which alias the packed rows)
+            tok = (weakref.ref(replay_buffer), replay_buffer._writes, replay_buffer._rows._version)
             flags = hb.TS_CONTINUE if self._ts_token == tok else 0
             rc = lib.iqlhip_train_steps(self._ctx, rows_ptr, ld, size, batch_size, tab.ctypes.data, k,
                                         seed, self.total_it * half, flags, stream)
