@@ -295,7 +295,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
     sb += (size_t)c->n_rt_max * ((size_t)HID * c->L.net[n].k_in + HID);
   }
   HIPCHK(dalloc(&c->sc.slab_b, sb));
-  HIPCHK(dalloc(&c->sc.loss_parts, 4 * 64));
+  HIPCHK(dalloc(&c->sc.loss_parts, 2 * 4 * 64));      // [4 losses][64 chunks / row blocks] (+ a second set: the large-batch path's totals)
   HIPCHK(dalloc(&c->pi_t, (size_t)MB * 65));
   HIPCHK(dalloc(&c->sc.losses, 4));
   HIPCHK(dalloc(&c->flat_tmp, (size_t)c->L.n_params + 4));
@@ -462,8 +462,8 @@ extern "C" int iqlhip_set_precision(iqlhip_ctx* c, int mode) {
     HIPCHK(hipMalloc((void**)&c->tsh, (size_t)up(c->L.n_target, 64) * sizeof(__bf16)));
     // scratch of the large-batch backward (iqlhip_lb_kernels.h)
     const size_t MB = (size_t)c->dims.max_batch;
-    HIPCHK(hipMalloc((void**)&c->dh1g, (8 * MB * HID + MB * 32 + MB * LB_XLD + 4 * 65536) * sizeof(__bf16)));
-    HIPCHK(hipMemset(c->dh1g, 0, (8 * MB * HID + MB * 32 + MB * LB_XLD + 4 * 65536) * sizeof(__bf16)));
+    HIPCHK(hipMalloc((void**)&c->dh1g, (8 * MB * HID + MB * 32 + MB * LB_XLD + 4 * 65536 + 8192) * sizeof(__bf16)));
+    HIPCHK(hipMemset(c->dh1g, 0, (8 * MB * HID + MB * 32 + MB * LB_XLD + 4 * 65536 + 8192) * sizeof(__bf16)));
     HIPCHK(hipMalloc((void**)&c->wimg, (size_t)6 * IMG_STRIDE * sizeof(__bf16)));
     HIPCHK(hipMemset(c->wimg, 0, (size_t)6 * IMG_STRIDE * sizeof(__bf16)));
     HIPCHK(hipMalloc((void**)&c->slab_x, (size_t)64 * c->L.n_params * sizeof(float)));
@@ -704,7 +704,8 @@ static UpdParams make_upd(const iqlhip_ctx* c, const iqlhip_step_scalars* sc, in
     u.n_chunk = gm.n_cg;
     u.slab_x = c->slab_x;
     u.n_x = gm.nbb;
-    u.n_loss = gm.nbb;
+    u.loss_parts = c->sc.loss_parts + 256;      // (entry 0 of each row: the total, summed by the GEMM launch's reduction job)
+    u.n_loss = 1;
   }
   u.batch_rows = rows;
   u.sched = nullptr;

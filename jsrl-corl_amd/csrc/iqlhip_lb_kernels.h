@@ -74,6 +74,10 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ bf16x4 lds_tr4(const __bf16* ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)ptr);
+}
+
 __device__ __forceinline__ bf16x4 cvt4(const f32x4 v) {
   bf16x4 r;
 #pragma unroll
@@ -102,6 +106,20 @@ __device__ __forceinline__ void iql_w1t_build(const StepParams& p, __bf16* w1t, 
     }
     __syncthreads();
     *(bf16x8*)(w1t + (unsigned)(net * 65536 + ((w * 4 + (tid >> 6)) * 8 + kb) * 512 + (tid & 63) * 8)) = *(const bf16x8*)(stage + tid * 8);
+  }
+  // the policy's W2 as the A operand of dH1^T = W2^T . dY^T (m = j = 64 w + 16 jt + l15, k = dim 8 g + e; zero beyond the
+  // action dims), behind the four W1 images: 4 slabs x 4 tiles x 64 lanes x 8 — one 16-byte load per tile in the row kernel
+  // instead of eight scalar gathers
+  for (int w = blk; w < 4; w += nblk) {
+    const int jt = tid >> 6, ln = tid & 63, D = p.net[IQLHIP_NET_PI].d;
+    float t8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int dd = 8 * (ln >> 4) + e;
+      const float v = p.net[IQLHIP_NET_PI].w2[(unsigned)(min(dd, D - 1) * HID + 64 * w + 16 * jt + (ln & 15))];
+      t8[e] = (dd < D) ? v : 0.f;
+    }
+    *(bf16x8*)(w1t + (unsigned)(4 * 65536 + ((w * 4 + jt) * 64 + ln) * 8)) = pack8s(t8);
   }
 }
 
@@ -587,12 +605,11 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   // W2: scalar nets — the lane's 16 columns j = 64 w + 16 jt + 4 g + reg; policy — A operand of dH1^T = W2^T . dY^T
   // (m = j = 64 w + 16 jt + l15, k = dim 8 g + e)
   f32x4 w2q[4];
-  float w2s[4][8];
+  bf16x8 w2A[4];      // (the image of the policy's W2, iql_w1t_build; loaded — and ignored — by the scalar nets' blocks too)
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     w2q[jt] = *(const f32x4*)(w2 + (unsigned)(64 * wave + 16 * jt + 4 * g));
-#pragma unroll
-    for (int e = 0; e < 8; ++e) w2s[jt][e] = w2[(unsigned)(min(8 * g + e, D - 1) * HID + 64 * wave + 16 * jt + l15)];
+    w2A[jt] = *(const bf16x8*)(a.w1t + (unsigned)(4 * 65536 + ((wave * 4 + jt) * 64 + lane) * 8));
   }
   // W1 as the B operand of dH0 = dH1 . W1 (k = j = 32 kb + 8 g + e, n = column 64 w + 4 l15 + tb), from the transposed
   // image the forward's idle blocks built (iql_w1t_build): a fragment load is 1 KB of consecutive memory
@@ -602,15 +619,21 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
       bwf[tb][kb] = *(const bf16x8*)(w1t + (unsigned)((((wave * 4 + tb) * 8 + kb) * 64 + lane) * 8));
-  bf16x8 w2A[4];      // (packed behind the first tile's first barrier: its inputs are the last small loads to arrive)
+  // the block's COLUMN sums over its rows — db1 = sum_r dH1, the scalar nets' dW2 = sum_r dy H1, db0 = sum_r dH0 — on the
+  // matrix cores: [1 .. 1] (or [dy]) . tile, the tile read transposed from the LDS image it sits in anyway
+  // (ds_read_b64_tr_b16).  Every accumulator row then holds the same column sums: register 0 of lane l15 (any g) is column
+  // 64 w + 16 t + l15's — no cross-lane reduction at the end, no per-tile vector-ALU adds (as per-lane partial sums with a
+  // DPP / LDS reduction this cost ~4 k cycles at the end of every block).
+  f32x4 sum1[4], sum2[4], sum0[4];
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) w2A[jt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-  // the block's sums over its rows
-  f32x4 db1p[4], dw2p[4];       // the lane's columns 64 w + 16 jt + 4 g .., over the rows its accumulators hold
-  f32x4 db0p = (f32x4){0.f, 0.f, 0.f, 0.f};      // the lane's columns 64 w + 4 l15 + tb of dH0, over its rows
+  for (int t = 0; t < 4; ++t) { sum1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; sum2[t] = sum1[t]; sum0[t] = sum1[t]; }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.f;
+  const int q4 = l15 >> 2, p4 = l15 & 3;
+  // B operand of a column-sum product: rows 8 g .. 8 g + 7, column c0 + l15 of a [32][H0B_LD] bf16 tile
+#define COLSUM_B(tile_, c0_) cat8(lds_tr4((tile_) + (8 * g + q4) * H0B_LD + (c0_) + 4 * p4), lds_tr4((tile_) + (8 * g + 4 + q4) * H0B_LD + (c0_) + 4 * p4))
   f32x4 pb2 = (f32x4){0.f, 0.f, 0.f, 0.f}, pls = pb2;      // policy: dims 4 xc .. over rows xr of the block's tiles
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) { db1p[jt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dw2p[jt] = db1p[jt]; }
   float accA = 0.f, accB = 0.f, accb2 = 0.f;      // loss sums (scalar nets: threads < 32; policy: threads xc == 0), scalar db2
   // ---- the block's sums -> its slab (arena layout).  Run in FRONT of the last tile's dH0 copy-out (LDS region of its own):
   // behind it, the first registers it touches were the copy-out stores' sources, and the block waited ~4 k cycles for
@@ -618,28 +641,15 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   auto block_sums = [&]() {
   float* pip = (float*)(dys + 32);     // [2][4 waves][32] policy db2 / dlog_std partials
   float* rsm = pip + 2 * 4 * 32;       // [16]
-  // column sums over the lanes that hold the same columns, in registers: db1 / scalar dW2 — the 16 lanes l15 of a row
-  // (four rotations within the row, DPP: every lane ends up with the row's sum); db0 — the four rows g (two shuffles)
+  if (g == 0) {
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      db1p[jt][reg] = row16_sum(db1p[jt][reg]);
-      dw2p[jt][reg] = row16_sum(dw2p[jt][reg]);
-    }
-#pragma unroll
-  for (int tb = 0; tb < 4; ++tb) {
-    db0p[tb] += __shfl_xor(db0p[tb], 16);
-    db0p[tb] += __shfl_xor(db0p[tb], 32);
-  }
-  if (l15 == 0) {
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      *(f32x4*)(slabX + go.b1 + 64 * wave + 16 * jt + 4 * g) = db1p[jt];
-      if (!is_pi) *(f32x4*)(slabX + go.w2 + 64 * wave + 16 * jt + 4 * g) = dw2p[jt];
+    for (int t = 0; t < 4; ++t) {
+      const int col = 64 * wave + 16 * t + l15;
+      slabX[go.b1 + col] = sum1[t][0];
+      if (!is_pi) slabX[go.w2 + col] = sum2[t][0];
+      slabX[go_b0 + col] = sum0[t][0];
     }
   }
-  if (g == 0) *(f32x4*)(slabX + go_b0 + 64 * wave + 4 * l15) = db0p;
   if (is_pi) {
     // dims 4 xc .. of the thread, over the wave's 8 row groups (lanes 8 apart), then over the four waves through LDS
 #pragma unroll
@@ -711,15 +721,6 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
     if (stamped) STAMP(p, 2);
     __syncthreads();
     if (stamped) STAMP(p, 3);
-    if (first) {
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        float t8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t8[e] = (8 * g + e < D) ? w2s[jt][e] : 0.f;
-        w2A[jt] = pack8s(t8);
-      }
-    }
     // ---- dH1 tile [32][256]: (dY . W2) masked by H1 > 0; lane: rows 16 r2 + l15, columns 64 w + 16 jt + 4 g ..
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
@@ -738,14 +739,25 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
         for (int reg = 0; reg < 4; ++reg) {
           const float h = (float)hmk[reg];
           o[reg] = (h > 0.f) ? pre[reg] * dscale : 0.f;
-          dw2p[jt][reg] = fmaf(dyr, h, dw2p[jt][reg]);      // (scalar nets: dW2 = sum_r dy H1; policy: dyr = 0)
         }
-        db1p[jt] += o;
         *(bf16x4*)(dH1b + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g) = cvt4(o);
       }
     }
     __syncthreads();
     if (stamped) STAMP(p, 4);
+    // column sums of the dH1 tile; scalar nets: of dy . H1 (A = the tile's 32 dy, the same in every row m)
+    {
+      bf16x8 Ady = ones;
+      if (!is_pi) {
+        const f32x4 ya = *(const f32x4*)(dys + 8 * g), yb = *(const f32x4*)(dys + 8 * g + 4);
+        Ady = pack8(ya, yb);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sum1[t] = MFMA_BF16(ones, COLSUM_B(dH1b, 64 * wave + 16 * t), sum1[t]);
+        if (!is_pi) sum2[t] = MFMA_BF16(Ady, COLSUM_B(H1t, 64 * wave + 16 * t), sum2[t]);
+      }
+    }
     // ---- dH0 = dH1 . W1: the wave's 64 columns over all 256 k
     {
       bf16x8 Ad[2][8];
@@ -776,7 +788,6 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
 #pragma unroll
           for (int tb = 0; tb < 4; ++tb) {
             const float v = ((float)T.hm[r2][reg][tb] > 0.f) ? acc[r2][tb][reg] * dscale : 0.f;      // rows >= B carry 0
-            db0p[tb] += v;
             o[tb] = (__bf16)v;
           }
           *(bf16x4*)(dH0b + (16 * r2 + 4 * g + reg) * H0B_LD + 64 * wave + 4 * l15) = o;
@@ -786,6 +797,8 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
     if (rt + nbb < n_rt) issue(T, rt + nbb);
     __syncthreads();
     if (stamped) STAMP(p, 6);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sum0[t] = MFMA_BF16(ones, COLSUM_B(dH0b, 64 * wave + 16 * t), sum0[t]);      // column sums of the dH0 tile
     if (rt + nbb >= n_rt) block_sums();      // (the block's last tile)
     // dH1 / dH0 rows -> memory (operands of dW1 = dH1^T . H0, dW0 = dH0^T . X): the tile's last instructions — a register
     // that was a store's source is not reused before the store has completed (~4 k cycles)
@@ -811,6 +824,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   RT_STAMP(p, 14, rt_entry_);
   RT_STAMP(p, 15, iql_realtime());
 #undef LBROW
+#undef COLSUM_B
 }
 
 // ---------------------------------------------------------------------------
@@ -828,9 +842,6 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
 // tools/microbench/tr_read_check.hip).
 #define LB_GLD 72
 #define LB_NJOB 28          // per net and chunk group; job 28 exists once per net (chunk group 0 only): see below
-__device__ __forceinline__ bf16x4 lds_tr4(const __bf16* ptr) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)ptr);
-}
 __global__ __launch_bounds__(256) void iql_bwd_gemm_kernel(StepParams p, LbArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 Ps[2][64 * LB_GLD];
   __shared__ __attribute__((aligned(16))) __bf16 Qs[2][64 * LB_GLD];
@@ -862,6 +873,22 @@ __global__ __launch_bounds__(256) void iql_bwd_gemm_kernel(StepParams p, LbArgs 
         for (int j = 0; j < 8; ++j) if (r0 + j < nbb) sum += v[j];
       }
       *(f32x4*)(dst + e) = sum;
+    }
+    // ... and the row blocks' loss sums (loss_parts[k][0 .. nbb)) into entry 0 of a second set of four rows, which is all
+    // the update kernel then reads (its thread 0 otherwise walks nbb entries per loss on the kernel's critical path).
+    // Wave 0 of the V block: loss 0; of the Q1 block: losses 1 and 2; of the policy block: loss 3.  Fixed order.
+    if (threadIdx.x < 64) {
+      float* lp = p.sc.loss_parts;
+      const int lane = threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool mine = (k == 0 && net == IQLHIP_NET_V) || ((k == 1 || k == 2) && net == IQLHIP_NET_Q1) || (k == 3 && net == IQLHIP_NET_PI);
+        if (!mine) continue;
+        float v = (lane < nbb) ? lp[k * 64 + lane] : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) lp[256 + k * 64] = v;
+      }
     }
     return;
   }
@@ -948,20 +975,35 @@ __global__ __launch_bounds__(256) void iql_bwd_gemm_kernel(StepParams p, LbArgs 
   GEMM_STORE(plA, qlA, 0, 0);
   __syncthreads();
   STAMP(p, 1);
-  // (stages come in pairs: even stages live in LDS buffer 0 / register set A, odd ones in buffer 1 / set B)
-  for (int s = 0; s < n_stage; s += 2) {
+  // (stages come in pairs: even stages live in LDS buffer 0 / register set A, odd ones in buffer 1 / set B.  The main loop
+  //  runs while both look-ahead loads are inside the range — straight-line, no branch around a load; the last one to three
+  //  stages follow without loads behind the range: the epilogue would wait for them)
+  int s = 0;
+  for (; s + 3 < n_stage; s += 2) {
     GEMM_LOAD(plA, qlA, s + 2);
     GEMM_STAGE(0);
     if (s == 0) STAMP(p, 4);
-    GEMM_STORE(plB, qlB, min(s + 1, n_stage - 1), 1);
+    GEMM_STORE(plB, qlB, s + 1, 1);
     if (s == 0) STAMP(p, 5);
     __syncthreads();
     if (s == 0) STAMP(p, 6);
-    if (s + 1 >= n_stage) break;
     GEMM_LOAD(plB, qlB, s + 3);
     GEMM_STAGE(1);
-    GEMM_STORE(plA, qlA, min(s + 2, n_stage - 1), 0);
+    GEMM_STORE(plA, qlA, s + 2, 0);
     __syncthreads();
+  }
+  const int left = n_stage - s;      // 1, 2 or 3: stage s is in buffer 0, stage s + 1 (if any) in register set B
+  if (left == 3) GEMM_LOAD(plA, qlA, s + 2);
+  GEMM_STAGE(0);
+  if (left >= 2) {
+    GEMM_STORE(plB, qlB, s + 1, 1);
+    __syncthreads();
+    GEMM_STAGE(1);
+    if (left == 3) {
+      GEMM_STORE(plA, qlA, s + 2, 0);
+      __syncthreads();
+      GEMM_STAGE(0);
+    }
   }
   STAMP(p, 2);
   // ---- the tile -> this chunk group's slab: D[m = 4 g + reg][n = l15] of tile (i, j) = C[32 wm + 16 i + 4 g + reg][32 wn + 16 j + l15]
