@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
 
   // ---- the 32 packed rows of a tile: thread (row tid >> 3, float4 (tid & 7) + 8 q of the instance's input columns)
   const int xr = tid >> 3, xc = tid & 7;
-  f32x4 xv[NKB];
+ f32x4 xv[NKB];
+  unsigned xsh[NKB];      // (the last floats of the batch are read from its last 16 bytes: the wanted elements sit xsh places up)
   int x_row = 0;          // the batch row this thread's X values belong to (x_store)
   auto x_issue = [&](int rt) {
     const unsigned row = (unsigned)min(rt * RT_ROWS + xr, B - 1);
@@ -207,13 +208,8 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
       const int c = min(4 * (xc + 8 * q), (k0 - 1) & ~3);
       const unsigned want = row * (unsigned)ld + (unsigned)(xoff + c);
       const unsigned idx = min(want, xtotal - 4u);
-      const unsigned sh = want - idx;
-      const f32x4 v = *(const f32x4u*)(xb + idx);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a1 = (j + 1 < 4) ? v[(j + 1) & 3] : 0.f, a2 = (j + 2 < 4) ? v[(j + 2) & 3] : 0.f, a3 = (j + 3 < 4) ? v[(j + 3) & 3] : 0.f;
-        xv[q][j] = (sh == 0u) ? v[j] : ((sh == 1u) ? a1 : ((sh == 2u) ? a2 : a3));
-      }
+      xsh[q] = want - idx;
+      xv[q] = *(const f32x4u*)(xb + idx);      // (ISSUE only: the shift is applied in x_store — used here, every load was waited for on the spot)
     }
   };
   auto x_store = [&]() {
@@ -221,9 +217,15 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
     for (int q = 0; q < NKB; ++q) {
       if (q < nkb) {
         const int c = 4 * (xc + 8 * q);
+        const f32x4 v = xv[q];
+        const unsigned sh = xsh[q];
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (__bf16)((c + j < k0) ? xv[q][j] : 0.f);     // columns >= k0: other fields of the row
+        for (int j = 0; j < 4; ++j) {
+          const float a1 = (j + 1 < 4) ? v[(j + 1) & 3] : 0.f, a2 = (j + 2 < 4) ? v[(j + 2) & 3] : 0.f, a3 = (j + 3 < 4) ? v[(j + 3) & 3] : 0.f;
+          const float xj = (sh == 0u) ? v[j] : ((sh == 1u) ? a1 : ((sh == 2u) ? a2 : a3));
+          o[j] = (__bf16)((c + j < k0) ? xj : 0.f);     // columns >= k0: other fields of the row
+        }
         *(bf16x4*)(Xb + xr * XLD + c) = o;
         xo[q] = o;
       }
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
     b2v[c] = np.b2[d];
     lsr[c] = lsp[d];
   }
+  __builtin_amdgcn_sched_barrier(0);      // (the scheduler must not move the W1 stream in front of the small loads above)
   // (requested last: the biggest and the last needed)
   // layer 1: A = W1 rows (bf16 shadow) of the same 64 units, all 256 k: 32 fragments of 8 contiguous k
   bf16x8 w1f[4][8];
@@ -293,7 +296,9 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   float ivar[4], lsc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    lsc[c] = (is_pi && gauss) ? fminf(fmaxf(lsr[c], ls_min), ls_max) : 0.f;
+    // (computed by every instance, from whatever lsp addressed: with the value used only under `is_pi && gauss` hipcc sinks
+    //  the LOAD into that branch — behind the W1 stream — and waits there for everything in flight)
+    lsc[c] = fminf(fmaxf(lsr[c], ls_min), ls_max);
     const float sig = expf(lsc[c]);
     ivar[c] = 1.f / (sig * sig);
   }
@@ -600,6 +605,9 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   // (the raw log_std of dim tid, for the block's last lines: loaded HERE, with the first batch — left at its use the
   //  compiler hoists the load in front of the tile loop and waits for everything in flight, the whole W1 stream, there)
   const float lsr_e = ((is_pi && gauss) ? log_std : w2)[min(tid, D - 1)];
+  // (hipcc's scheduler moved the 44 weight loads below IN FRONT of these — vmcnt retires in order, so the first tile's loss
+  //  arithmetic then waited for the whole 128 KB weight stream; nothing crosses this line)
+  __builtin_amdgcn_sched_barrier(0);
   // ---- the wave's operands for the whole block (requested BEHIND the first tile's inputs: the loss arithmetic and the
   // dH1 tile run under this stream)
   // W2: scalar nets — the lane's 16 columns j = 64 w + 16 jt + 4 g + reg; policy — A operand of dH1^T = W2^T . dY^T
