@@ -51,7 +51,6 @@ PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_summary.js
 # tools/profile_round.sh with BENCH_ARGS set
 PMC_SUMMARIES_C5 = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_config5.json",)]
 LB_MIN_ROWS = 512              # bf16 batches above this take the large-batch kernels (csrc/iqlhip_lb_kernels.h)
-COMPULSORY_NOTE = "compulsory HBM bytes per step = the row gather, batch x row stride (43 KB at obs 17 / act 6 / 256 rows): the state is cache-resident"
 
 
 def flops(S, A, B):
@@ -401,7 +400,9 @@ def run_rank(args, world: int) -> int:
         roof = {"bound": "mfma", "kernel": kernel_name, "achieved": round(ach, 3), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None if traffic is None else round(traffic),
-                "traffic_kind": "fabric bytes (L2 <-> memory side, Infinity-Cache hits included), not HBM bytes; " + COMPULSORY_NOTE,
+                "traffic_kind": "fabric bytes per launch of this kernel (L2 <-> memory side, Infinity-Cache hits included), not HBM bytes; "
+                                f"compulsory HBM bytes per step = the row gather = batch x row stride = {B * ((2 * S + A + 2 + 3) // 4 * 4) * 4} B "
+                                "(parameters, optimiser state and activations are cache-resident)",
                 "traffic_source": None if traffic is None else f"{pmc_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE; not measured in this run)",
                 "mfma_util_pmc": None if mfma_util is None else round(mfma_util, 4),
                 "mfma_util_source": None if mfma_util is None else pmc_src,

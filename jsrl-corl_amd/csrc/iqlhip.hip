@@ -850,9 +850,11 @@ static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
   const int nb = 8 * (int)((seg_max + 2047) / 2048);
   const bool peer = u.n_peer > 0;
 #define UPD_LAUNCH(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P>), dim3(nb), dim3(256), 0, st, u)
-#define UPD_LAUNCH_LB(T) hipLaunchKernelGGL((iql_update_kernel<T, false, true>), dim3(nb), dim3(256), 0, st, u)
-  if (u.slab_x && !peer && !u.flat_grads) {      // large-batch bf16 step (an exchanged gradient arrives flat: the plain kernels)
-    if (u.sched) UPD_LAUNCH_LB(true); else UPD_LAUNCH_LB(false);
+#define UPD_LAUNCH_LB(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P, true>), dim3(nb), dim3(256), 0, st, u)
+  if (u.slab_x) {      // large-batch bf16 step: the LB instantiations (gradient from the chunk-group slabs unless an exchange
+                       // delivered it flat; the operand images of W0 / W1 written next to the bf16 shadows)
+    if (u.sched) { if (peer) UPD_LAUNCH_LB(true, true); else UPD_LAUNCH_LB(true, false); }
+    else         { if (peer) UPD_LAUNCH_LB(false, true); else UPD_LAUNCH_LB(false, false); }
   } else if (u.sched) { if (peer) UPD_LAUNCH(true, true); else UPD_LAUNCH(true, false); }
   else              { if (peer) UPD_LAUNCH(false, true); else UPD_LAUNCH(false, false); }
 #undef UPD_LAUNCH

@@ -2621,7 +2621,7 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
       *(f32x4*)tp = t;
       if (u.tsh) st4<true>((float*)u.tsh, (unsigned)(e - u.L.target_src), t);
     }
-    if (u.wimg) {      // bf16 path: the operand images of W1 / W0 (W1 leads a net's segment)
+    if (LB && u.wimg) {      // large-batch bf16 path: the operand images of W1 / W0 (W1 leads a net's segment)
       const NetWords nw = net_words(u, net);
       img_store4(u.wimg + (size_t)net * IMG_STRIDE, e, seg_b, nw.w0, nw.k_in, pw);
       if (is_q) img_store4(u.wimg + (size_t)(3 + net) * IMG_STRIDE, e, seg_b, nw.w0, nw.k_in, t);      // (nets 1, 2 -> slots 4, 5)

@@ -220,3 +220,28 @@ def test_head_modes_and_forward_layouts_agree(tmp_path):
         assert o["losses"] == outs[0]["losses"], variants[i]
         assert o["params"] == outs[0]["params"], variants[i]
     assert len(outs[0]["losses"]) == 98 and np.all(np.isfinite(np.array(outs[0]["losses"])))
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
+def test_exchange_world1_equals_plain_steps_on_the_large_batch_bf16_path(gloo_world1, exchange):
+    """BASELINE configs[4] is the data-parallel bf16 run: 1 024 rows per rank take the large-batch kernels
+    (csrc/iqlhip_lb_kernels.h), whose gradient reaches the update kernel flat (flatten -> exchange) instead of through the
+    chunk-group slabs, and whose update must still keep the forward's operand images current.  With a 1-rank group both
+    exchanges land on the plain step's losses and parameters bit for bit, eagerly and through the chunk graphs."""
+    S, A, B = 39, 28, 1024
+    params, buf, _ = _mk(141, S=S, A=A, N=4000)
+    from hip_helpers import build_hip_trainer
+    hyper = {"iql_tau": 0.8, "beta": 3.0, "discount": 0.99, "tau": 0.005}
+    new = lambda: build_hip_trainer(params, S, A, True, hyper, LRS, 1000)
+    plain, dpt = new(), new()
+    plain.set_precision("bf16")
+    dpt.set_precision("bf16")
+    dpt.enable_data_parallel(exchange=exchange)
+    batch = buf.gather(torch.arange(B, device="cuda"))
+    for _ in range(3):                       # (three steps: a stale operand image would show from the second on)
+        assert plain.train(batch) == dpt.train(batch)
+    la = plain.train_steps(buf, 6, B, seed=5)
+    lb = dpt.train_steps(buf, 6, B, seed=5)
+    assert np.array_equal(la, lb)
+    _same_params(plain, dpt)
+    assert dpt.exchange_status()["timed_out_step"] == 0
