@@ -2,8 +2,8 @@
 bf16 precision — BASELINE configs[4]'s per-GPU share of 1 024 rows and its whole 8 192-row batch on one GPU).
 
 Checker: the oracle (oracle/iql_oracle.py, pinned to the reference's own outputs by tests/test_oracle_golden.py) on the
-same seeded inputs.  Tolerances are the bf16 statement of SURVEY §8d / north_star: losses rel <= 2e-2 against the fp32
-values; gradients within 1e-1 in relative L2 norm per tensor (bf16 operands carry 8 significant bits), head-bias /
+same seeded inputs.  Tolerances are the bf16 statement of SURVEY §8d / north_star: losses rel <= 5e-3 against the fp32
+values; gradients within 8.5e-2 in relative L2 norm per tensor (bf16 operands carry 8 significant bits), head-bias /
 log_std gradients — means of signed residuals, heavy cancellation — within 2e-2 of the residual scale.  Determinism:
 the multi-step driver's chunk graphs equal eager steps on the same indices bit for bit, as on the fp32 path.
 """
@@ -31,7 +31,12 @@ def _case(S, A, B, seed, gaussian=True):
     return params, batch, hyper, lrs
 
 
-def _check_grads(got, want_all, tol=1e-1):
+# (round 4: tightened from 2e-2 / 1e-1 to 2.5x / 1.13x the worst observed over every bf16 case of the suite: 2.0e-3 / 7.55e-2)
+LOSS_RTOL = 5e-3
+GRAD_RL2 = 8.5e-2
+
+
+def _check_grads(got, want_all, tol=GRAD_RL2):
     worst = 0.0
     for net, tensors in want_all.items():
         for t, want in tensors.items():
@@ -67,13 +72,14 @@ def test_lb_bf16_step_against_the_oracle(S, A, B, gaussian):
     tb = to_tb(batch)
     grads, lw = unflat(tr, tr.flat_gradient(tb))
     for got, want in zip(lw, want_l):
-        assert abs(got - want) <= 2e-2 * abs(want), (lw, want_l)
+        assert abs(got - want) <= LOSS_RTOL * abs(want), (lw, want_l)
     worst = _check_grads(grads, ref["grads"])
     assert worst > 1e-5          # the bf16 path really ran (fp32 would sit at ~1e-7)
-    print(f"S={S} A={A} B={B}: worst relative-L2 gradient error vs oracle {worst:.3e}")
+    worst_l = max(abs(g - w) / abs(w) for g, w in zip(lw, want_l))
+    print(f"S={S} A={A} B={B}: worst relative-L2 gradient error vs oracle {worst:.3e}, worst loss error {worst_l:.3e}")
     log = tr.train(tb)
     for got, want in zip([log["value_loss"], log["q_loss"], log["actor_loss"]], want_l):
-        assert abs(got - want) <= 2e-2 * abs(want)
+        assert abs(got - want) <= LOSS_RTOL * abs(want)
     # the step moved every tensor (the update kernel's large-batch gradient sources are wired to every arena range)
     after = read_params(tr)
     for net in ("vf", "q1", "q2", "pi"):

@@ -354,8 +354,8 @@ def test_dropout_in_graph_steps_is_seeded_and_varies_per_step():
 @pytest.mark.parametrize("name", ["g1_S17A6_gauss_b3", "g1_S39A28_gauss_b10", "g1_S29A8_det_b10"])
 def test_bf16_operand_mode_tracks_fp32_reference(name):
     """BASELINE config 5's "MFMA bf16 path": bf16 operands / fp32 accumulate in the layer-0 / layer-1 / dW1 / dH0 / dW0
-    products.  Tolerance: losses rel <= 2e-2 single-step vs the fp32 reference fixture; gradients within
-    1e-1 in relative L2 norm per tensor (bf16 operands carry 8 significant bits; observed worst 6.9e-2)."""
+    products.  Tolerance (SURVEY §8d): losses rel <= 5e-3 single-step vs the fp32 reference fixture (observed worst 9e-4);
+    gradients within 8.5e-2 in relative L2 norm per tensor (bf16 operands carry 8 significant bits; observed worst 7.55e-2)."""
     build, _, _, _, to_tb, unflat = _hip()
     z, meta = load_golden(name)
     params, batch, hyper = single_step_inputs(meta)
@@ -363,7 +363,7 @@ def test_bf16_operand_mode_tracks_fp32_reference(name):
     tr.set_precision("bf16")
     tb = to_tb(batch)
     grads, lw = unflat(tr, tr.flat_gradient(tb))
-    assert_losses(lw, z["losses"], 2e-2)
+    assert_losses(lw, z["losses"], 5e-3)
     from oracle import iql_oracle as O
     info = O.iql_losses_and_grads(params, batch, hyper)
     worst = 0.0
@@ -377,10 +377,12 @@ def test_bf16_operand_mode_tracks_fp32_reference(name):
                 continue
             rel = float(np.linalg.norm(g - want) / max(np.linalg.norm(want), 1e-30))
             worst = max(worst, rel)
-            assert rel <= 1e-1, (n, k, rel)
+            assert rel <= 8.5e-2, (n, k, rel)
     assert worst > 1e-5          # the mode really is active (fp32 would sit at ~1e-7)
+    worst_l = max(abs(float(g) - float(w)) / abs(float(w)) for g, w in zip(lw, z["losses"]))
+    print(f"{name}: bf16 worst relative-L2 gradient error {worst:.3e}, worst loss error {worst_l:.3e}")
     log = tr.train(tb)
-    assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"], 2e-2)
+    assert_losses([log["value_loss"], log["q_loss"], log["actor_loss"]], z["losses"], 5e-3)
     tr.set_precision("f32")
     log2 = tr.train(tb)
     assert all(np.isfinite(v) for v in log2.values())
