@@ -2064,6 +2064,13 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
     // [dW0 | db0][i][kc] partial = sum_r dH0[r][i] * [X | 1][r][kc].  A = [X|1] (m = kc), B = dH0 (n = i):
     // a lane's 4 accumulator registers are 4 consecutive kc of one i.  This wave: i in [i0 + 16*wave, +16).
     {
+      // (multi-slice blocks: this block's lane masks — kc < k0, kc == k0, kc0 + 3 < k0 per column tile and register — are
+      //  loop-invariant; hipcc hoisted all ~80 of them, as 64-bit masks, in front of the slice loop and spilled 170-180
+      //  SGPRs to keep them alive across it.  A per-iteration copy of k0 the compiler cannot see through keeps them where
+      //  they are used.  The outer name is shadowed on purpose.)
+      int k0_ = k0;
+      if constexpr (MULTI) asm volatile("" : "+s"(k0_));
+      const int k0 = k0_;
       const int k1 = k0 + 1;
       const int nct = (k1 + 15) >> 4;
       f32x4 acc[9];
