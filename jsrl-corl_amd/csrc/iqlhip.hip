@@ -165,6 +165,7 @@ struct iqlhip_ctx {
   __bf16* wimg = nullptr;             // bf16 path: operand images of W1 / W0, [6][IMG_STRIDE] (iqlhip_kernels.h)
   int lb_enabled = 1;                 // diagnostic (IQLHIP_LB=0): keep the small-batch kernels at every batch size
   int lb_nbb_force = -1, lb_cpb_force = -1, lb_nbi_force = -1;   // diagnostic (IQLHIP_LB_NBB / _CPB / _NBI)
+  bool lb_csplit = true;              // IQLHIP_LB_CSPLIT=0: no column split of the row kernel at <= 1 024 rows (diagnostic)
   int lb_bwd_part = 0;                // iqlhip_debug_time_kernel only: 1 = launch the row kernel alone, 2 = the GEMM kernel alone
   size_t lds_bwd_lb = 0;
   // graph cache (a few (K,B,buffer) shapes: the steady chunk, the tail chunk, ...)
@@ -345,6 +346,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   if (const char* ov = getenv("IQLHIP_FWD_SPB_L2")) c->fwd_spb_force = std::max(0, std::min(2, atoi(ov)));   // diagnostic (tools/)
   if (const char* ov = getenv("IQLHIP_LB")) c->lb_enabled = atoi(ov) != 0;                                     // diagnostic (tools/)
   if (const char* ov = getenv("IQLHIP_LB_NBB")) c->lb_nbb_force = std::max(2, atoi(ov));
+  if (const char* ov = getenv("IQLHIP_LB_CSPLIT")) c->lb_csplit = atoi(ov) != 0;
   if (const char* ov = getenv("IQLHIP_LB_CPB")) c->lb_cpb_force = std::max(1, atoi(ov));
   if (const char* ov = getenv("IQLHIP_LB_NBI")) c->lb_nbi_force = std::max(2, atoi(ov));
   c->lds_fwd = fwd_fixed + (size_t)HID * w0_lds_k * sizeof(float) + (w0_lds_k > W0_LDS_MAX_K ? 4096 : 0);
@@ -380,7 +382,8 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   {
     // large-batch backward, row blocks: [dH1 tile | H1 tile | dH0 tile | dY | dy] (iql_bwd_rows_kernel)
     c->lds_bwd_lb = (size_t)(3 * 32 * H0B_LD + 32 * LB_DYLD) * 2 + 32 * 4 + (size_t)(2 * 4 * 32 + 16) * 4;      // (+ the block sums' partials)
-    HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd_lb));
+    HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd_lb));
+    HIPCHK(hipFuncSetAttribute((const void*)iql_bwd_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bwd_lb));
   }
   return IQLHIP_OK;
 }
@@ -596,7 +599,7 @@ static bool use_lb(const iqlhip_ctx* c, int rows) {
   if (c->fwd_spb_force >= 0 || c->bwd_spb_force >= 0) return false;      // (diagnostic layouts of the small-batch kernels)
   return c->dims.state_dim + c->dims.action_dim + 1 <= 16 * 5;           // [dW0 | db0] tiles a (b) block keeps in registers
 }
-struct LbGeom { int n_rt, n_chunk, nbi, nbb, cpb, n_cg; };
+struct LbGeom { int n_rt, n_chunk, nbi, nbb, cpb, n_cg, csplit; };
 static LbGeom lb_geom(const iqlhip_ctx* c, int rows) {
   LbGeom g;
   g.n_rt = (rows + RT_ROWS - 1) / RT_ROWS;
@@ -606,6 +609,9 @@ static LbGeom lb_geom(const iqlhip_ctx* c, int rows) {
   g.nbi = std::min(even_rt, c->lb_nbi_force > 0 ? (c->lb_nbi_force + 1) & ~1 : 32);
   // backward: a net's blocks live on its two XCDs (64 CUs): (b) blocks of up to n_rt / nbb row tiles, (a) blocks of cpb chunks
   g.nbb = std::min(std::min(even_rt, 64), c->lb_nbb_force > 0 ? (c->lb_nbb_force + 1) & ~1 : 64);
+  // up to 32 row tiles (1 024 rows): two blocks per tile, each half of the dH0 columns (iql_bwd_rows_kernel<true>) — a block
+  // per tile would leave half the chip idle.  IQLHIP_LB_CSPLIT=0: the one-block-per-tile form at every size (diagnostic).
+  g.csplit = (even_rt <= 32 && c->lb_nbb_force <= 0 && c->lb_csplit) ? 1 : 0;      // (nbb = even_rt then: one slab per tile)
   // GEMM blocks: 28 jobs per net and chunk group; about four chunk groups keep >= 400 blocks in flight
   g.cpb = c->lb_cpb_force > 0 ? std::min(c->lb_cpb_force, g.n_chunk) : std::max(1, std::min(8, g.n_chunk / 4));
   g.n_cg = (g.n_chunk + g.cpb - 1) / g.cpb;
@@ -787,7 +793,10 @@ static void launch_bwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t 
     const LbArgs a = lb_args(c, p.rows);
     const int kq = c->dims.state_dim + c->dims.action_dim;
     (void)kq;
-    if (c->lb_bwd_part != 2) hipLaunchKernelGGL(iql_bwd_rows_kernel, dim3(8 * (a.nbb / 2)), dim3(256), c->lds_bwd_lb, st, p, a);
+    if (c->lb_bwd_part != 2) {
+      if (lb_geom(c, p.rows).csplit) hipLaunchKernelGGL(iql_bwd_rows_kernel<true>, dim3(8 * a.nbb), dim3(256), c->lds_bwd_lb, st, p, a);
+      else hipLaunchKernelGGL(iql_bwd_rows_kernel<false>, dim3(8 * (a.nbb / 2)), dim3(256), c->lds_bwd_lb, st, p, a);
+    }
     if (c->lb_bwd_part != 1)
       hipLaunchKernelGGL(iql_bwd_gemm_kernel, dim3(8 * ((LB_NJOB * a.n_cg + 1 + 1) / 2)), dim3(256), 0, st, p, a);      // (+ 1: the reduction job)
     return;

@@ -529,16 +529,31 @@ struct LbTileIn {         // what a row block loads per 32-row tile
   bf16x8 h1q[4];          // the H1 tile [32][256] as a flat copy: 16 bytes tid + 256 q (-> LDS -> dH1's accumulator layout)
   bf16x4 hm[2][4];        // H0 in dH0's accumulator layout
 };
+// CS ("column split", batches of at most 32 row tiles = 1 024 rows, where a block per tile leaves half the chip idle and
+// a block is mostly the prologue that pulls the net's 128 KB W1 image through the CU's one vector-memory pipe): TWO blocks per
+// row tile, on the XCD of the tile's parity.  Both build the whole dH1 tile (all 256 j are the contraction index); block ch
+// then owns the dH0 columns [128 ch, 128 ch + 128) — half the W1 image, half the MFMAs, half the copy-out — wave w the combs
+// tb0, tb0 + 1 of 64-column slab 2 ch + (w >> 1).  Everything that belongs to the tile as a whole (dY, the loss sums, db1 /
+// db2 sums) is block 0's, the column sums db1 / dW2 are block 1's; the dH1 copy-out is shared by rows.  The two blocks share ONE slab of sums: block 1 writes
+// its half of db0 into it and nothing else (64 slabs instead of 32 made the GEMM launch's reduction job 0.7 us longer).
+template <bool CS>
 __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RT_ENTRY();
   const int bid = blockIdx.x;
   const int x = bid & 7;
   const int net = x & 3;
-  const int lb = (bid >> 3) * 2 + (x >> 2);
+  const int lbq = bid >> 3, hx = x >> 2;
+  const int ch = CS ? (lbq & 1) : 0;                        // the column half
+  const int lb = (CS ? (lbq >> 1) : lbq) * 2 + hx;          // the slab of sums / loss-sum entry (CS: shared by the tile's two blocks)
   if (lb >= a.nbb) return;
+  const int rt0 = lb;                                       // the block's first row tile ...
+  const int rts = a.nbb;                                    // ... and the stride to its next one
+  constexpr int NTB = CS ? 2 : 4;                           // column combs (n = 4 l15 + tb of a 64-column slab) per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
+  const int wq = CS ? (2 * ch + (wave >> 1)) : wave;        // the 64-column slab of W1 / dH0 this wave works on
+  const int tb0 = CS ? 2 * (wave & 1) : 0;                  // ... and its first column comb
   const int B = p.rows, MB = p.sc.max_batch;
   const NetPtrs np = p.net[net];
   const NetGrad go = p.go[net];
@@ -562,11 +577,11 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   const __bf16* w1t = a.w1t + net * 65536;
   const float ls_min = p.hy.log_std_min, ls_max = p.hy.log_std_max, beta = p.hy.beta, adv_max = p.hy.exp_adv_max;
   float* loss_parts = p.sc.loss_parts;
-  const int n_rt = a.n_rt, nbb = a.nbb;
+  const int n_rt = a.n_rt;
   PIN_P(pi_t); PIN_P(pi_g); PIN_P(pi_l); PIN_P(dyg); PIN_P(slabX); PIN_P(log_std); PIN_P(loss_parts); PIN_P(w2); PIN_P(w1t);
   PIN_P(H1g); PIN_P(H0g); PIN_P(dH1g); PIN_P(dH0g); PIN_P(heads); PIN_P(p.xb);
   PIN_S(go_b0); PIN_S(go.b1); PIN_S(go.w2); PIN_S(go.b2); PIN_S(go.log_std); PIN_S(ls_min); PIN_S(ls_max); PIN_S(beta); PIN_S(adv_max);
-  PIN_S(dscale); PIN_S(invB); PIN_S(n_rt); PIN_S(nbb); PIN_S(B); PIN_S(D); PIN_S(p.ld); PIN_S(p.S); PIN_S(p.A);
+  PIN_S(dscale); PIN_S(invB); PIN_S(n_rt); PIN_S(rts); PIN_S(B); PIN_S(D); PIN_S(p.ld); PIN_S(p.S); PIN_S(p.A);
   PIN_S(p.hy.iql_tau); PIN_S(p.hy.discount);
 #define LBROW(r) min((r), B - 1)
   STAMP_BASE(p, 2048 * 16);
@@ -595,13 +610,13 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
     for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)
-        s.hm[r2][reg] = *(const bf16x4*)(H0g + ((unsigned)LBROW(row0 + 16 * r2 + 4 * g + reg) * (unsigned)HID + (unsigned)(64 * wave + 4 * l15)));
+        s.hm[r2][reg] = *(const bf16x4*)(H0g + ((unsigned)LBROW(row0 + 16 * r2 + 4 * g + reg) * (unsigned)HID + (unsigned)(64 * wq + 4 * l15)));
   };
   LbTileIn T;
 #pragma unroll
   for (int i = 0; i < 6; ++i) T.in.h[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   T.in.r = 0.f; T.in.d = 0.f;
-  issue(T, lb);
+  issue(T, rt0);
   // (the raw log_std of dim tid, for the block's last lines: loaded HERE, with the first batch — left at its use the
   //  compiler hoists the load in front of the tile loop and waits for everything in flight, the whole W1 stream, there)
   const float lsr_e = ((is_pi && gauss) ? log_std : w2)[min(tid, D - 1)];
@@ -621,12 +636,12 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   }
   // W1 as the B operand of dH0 = dH1 . W1 (k = j = 32 kb + 8 g + e, n = column 64 w + 4 l15 + tb), from the transposed
   // image the forward's idle blocks built (iql_w1t_build): a fragment load is 1 KB of consecutive memory
-  bf16x8 bwf[4][8];
+  bf16x8 bwf[NTB][8];
 #pragma unroll
-  for (int tb = 0; tb < 4; ++tb)
+  for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
-      bwf[tb][kb] = *(const bf16x8*)(w1t + (unsigned)((((wave * 4 + tb) * 8 + kb) * 64 + lane) * 8));
+      bwf[tb][kb] = *(const bf16x8*)(w1t + (unsigned)((((wq * 4 + tb0 + tb) * 8 + kb) * 64 + lane) * 8));
   // the block's COLUMN sums over its rows — db1 = sum_r dH1, the scalar nets' dW2 = sum_r dy H1, db0 = sum_r dH0 — on the
   // matrix cores: [1 .. 1] (or [dy]) . tile, the tile read transposed from the LDS image it sits in anyway
   // (ds_read_b64_tr_b16).  Every accumulator row then holds the same column sums: register 0 of lane l15 (any g) is column
@@ -649,13 +664,33 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   auto block_sums = [&]() {
   float* pip = (float*)(dys + 32);     // [2][4 waves][32] policy db2 / dlog_std partials
   float* rsm = pip + 2 * 4 * 32;       // [16]
-  if (g == 0) {
+  if (CS && ch == 1) {      // (block-uniform) the second block of a tile: db1 / the scalar dW2 (the column sums over the dH1 and
+                            // H1 tiles, which it holds like block 0) and its 128 columns of db0, into the slab block 0 fills
+    if (g == 0) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = 64 * wave + 16 * t + l15;
-      slabX[go.b1 + col] = sum1[t][0];
-      if (!is_pi) slabX[go.w2 + col] = sum2[t][0];
-      slabX[go_b0 + col] = sum0[t][0];
+      for (int t = 0; t < 4; ++t) {
+        const int col = 64 * wave + 16 * t + l15;
+        slabX[go.b1 + col] = sum1[t][0];
+        if (!is_pi) slabX[go.w2 + col] = sum2[t][0];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) slabX[go_b0 + 128 + 32 * wave + 16 * t + l15] = sum0[t][0];
+    }
+    return;
+  }
+  if (g == 0) {
+    if (!CS) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int col = 64 * wave + 16 * t + l15;
+        slabX[go.b1 + col] = sum1[t][0];
+        if (!is_pi) slabX[go.w2 + col] = sum2[t][0];
+        slabX[go_b0 + col] = sum0[t][0];
+      }
+    }
+    if (CS) {      // db0 of block 0's 128 columns (the other 128, db1 and the scalar dW2: block 1, above)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) slabX[go_b0 + 32 * wave + 16 * t + l15] = sum0[t][0];
     }
   }
   if (is_pi) {
@@ -693,10 +728,10 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   };
   STAMP(p, 1);
 
-  for (int rt = lb; rt < n_rt; rt += nbb) {
+  for (int rt = rt0; rt < n_rt; rt += rts) {
     const int row0 = rt * RT_ROWS;
-    const bool first = (rt == lb);
-    const bool stamped = (rt == lb + LB_STAMP_TILE * nbb);      // (the tile whose phases the diagnostic build stamps)
+    const bool first = (rt == rt0);
+    const bool stamped = (rt == rt0 + LB_STAMP_TILE * rts);      // (the tile whose phases the diagnostic build stamps)
     // the H1 tile -> LDS
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -709,7 +744,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
         float v = 0.f, la_ = 0.f, lb_ = 0.f;
         if (row0 + tid < B) row_finish(p, net, T.in, &v, la_, lb_);
         dys[tid] = v;
-        accA += la_; accB += lb_; accb2 += v;
+        if (ch == 0) { accA += la_; accB += lb_; accb2 += v; }
       }
     } else {
       float w = 0.f;
@@ -721,10 +756,12 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
       const f32x4 dy4 = T.t4 * w;
       const bf16x4 dyb = cvt4(dy4);
       *(bf16x4*)(dYb + xr * LB_DYLD + 4 * xc) = dyb;
-      if (row0 + xr < B) *(bf16x4*)(dyg + (unsigned)((row0 + xr) * 32 + 4 * xc)) = dyb;
-      pb2 += dy4;
-      pls += T.g4 * w;
-      if (xc == 0) accA += w * T.lrow;
+      if (row0 + xr < B && ch == 0) *(bf16x4*)(dyg + (unsigned)((row0 + xr) * 32 + 4 * xc)) = dyb;
+      if (ch == 0) {
+        pb2 += dy4;
+        pls += T.g4 * w;
+        if (xc == 0) accA += w * T.lrow;
+      }
     }
     if (stamped) STAMP(p, 2);
     __syncthreads();
@@ -760,10 +797,12 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
         const f32x4 ya = *(const f32x4*)(dys + 8 * g), yb = *(const f32x4*)(dys + 8 * g + 4);
         Ady = pack8(ya, yb);
       }
+      if (ch == (CS ? 1 : 0)) {      // (CS: block 1's — block 0 carries the loss sums and the policy's db2 / dlog_std)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        sum1[t] = MFMA_BF16(ones, COLSUM_B(dH1b, 64 * wave + 16 * t), sum1[t]);
-        if (!is_pi) sum2[t] = MFMA_BF16(Ady, COLSUM_B(H1t, 64 * wave + 16 * t), sum2[t]);
+        for (int t = 0; t < 4; ++t) {
+          sum1[t] = MFMA_BF16(ones, COLSUM_B(dH1b, 64 * wave + 16 * t), sum1[t]);
+          if (!is_pi) sum2[t] = MFMA_BF16(Ady, COLSUM_B(H1t, 64 * wave + 16 * t), sum2[t]);
+        }
       }
     }
     // ---- dH0 = dH1 . W1: the wave's 64 columns over all 256 k
@@ -774,52 +813,64 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
         Ad[0][kb] = *(const bf16x8*)(dH1b + l15 * H0B_LD + 32 * kb + 8 * g);
         Ad[1][kb] = *(const bf16x8*)(dH1b + (16 + l15) * H0B_LD + 32 * kb + 8 * g);
       }
-      f32x4 acc[2][4];
+      f32x4 acc[2][NTB];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
+        for (int tb = 0; tb < NTB; ++tb) {
           acc[0][tb] = MFMA_BF16(Ad[0][kb], bwf[tb][kb], acc[0][tb]);
           acc[1][tb] = MFMA_BF16(Ad[1][kb], bwf[tb][kb], acc[1][tb]);
         }
       if (stamped) STAMP(p, 5);
-      // masked -> the row-major dH0 tile: a lane's 4 column tiles are 4 consecutive columns of row 16 r2 + 4 g + reg
+      // masked -> the row-major dH0 tile: a lane's column combs are consecutive columns of row 16 r2 + 4 g + reg
 #pragma unroll
       for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          bf16x4 o;
+          if constexpr (CS) {
+            const bf16x4 hmk = T.hm[r2][reg];
+            bf16x2 o;
 #pragma unroll
-          for (int tb = 0; tb < 4; ++tb) {
-            const float v = ((float)T.hm[r2][reg][tb] > 0.f) ? acc[r2][tb][reg] * dscale : 0.f;      // rows >= B carry 0
-            o[tb] = (__bf16)v;
+            for (int tb = 0; tb < 2; ++tb) {
+              const float hv = (tb0 == 0) ? (float)hmk[tb] : (float)hmk[2 + tb];
+              o[tb] = (__bf16)((hv > 0.f) ? acc[r2][tb][reg] * dscale : 0.f);      // rows >= B carry 0
+            }
+            *(bf16x2*)(dH0b + (16 * r2 + 4 * g + reg) * H0B_LD + 64 * wq + 4 * l15 + tb0) = o;
+          } else {
+            bf16x4 o;
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) {
+              const float v = ((float)T.hm[r2][reg][tb] > 0.f) ? acc[r2][tb][reg] * dscale : 0.f;      // rows >= B carry 0
+              o[tb] = (__bf16)v;
+            }
+            *(bf16x4*)(dH0b + (16 * r2 + 4 * g + reg) * H0B_LD + 64 * wave + 4 * l15) = o;
           }
-          *(bf16x4*)(dH0b + (16 * r2 + 4 * g + reg) * H0B_LD + 64 * wave + 4 * l15) = o;
         }
     }
     // the next tile's inputs: everything of this tile's has been consumed
-    if (rt + nbb < n_rt) issue(T, rt + nbb);
+    if (rt + rts < n_rt) issue(T, rt + rts);
     __syncthreads();
     if (stamped) STAMP(p, 6);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) sum0[t] = MFMA_BF16(ones, COLSUM_B(dH0b, 64 * wave + 16 * t), sum0[t]);      // column sums of the dH0 tile
-    if (rt + nbb >= n_rt) block_sums();      // (the block's last tile)
+    for (int t = 0; t < NTB; ++t)      // column sums of the dH0 tile (CS: of the block's half, two 16-column tiles per wave)
+      sum0[t] = MFMA_BF16(ones, COLSUM_B(dH0b, CS ? (128 * ch + 32 * wave + 16 * t) : (64 * wave + 16 * t)), sum0[t]);
+    if (rt + rts >= n_rt) block_sums();      // (the block's last tile)
     // dH1 / dH0 rows -> memory (operands of dW1 = dH1^T . H0, dW0 = dH0^T . X): the tile's last instructions — a register
     // that was a store's source is not reused before the store has completed (~4 k cycles)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < (CS ? 2 : 4); ++q) {      // (CS: rows 16 ch .. 16 ch + 15 of the dH1 tile both blocks hold)
       const int f = tid + 256 * q;
-      const int rl = f >> 5, col = 8 * (f & 31);
+      const int rl = (CS ? 16 * ch : 0) + (f >> 5), col = 8 * (f & 31);
       if (row0 + rl < B) *(bf16x8*)(dH1g + (unsigned)((row0 + rl) * HID + col)) = *(const bf16x8*)(dH1b + rl * H0B_LD + col);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < (CS ? 2 : 4); ++q) {      // (CS: the block's 128 columns of all 32 rows)
       const int f = tid + 256 * q;
-      const int rl = f >> 5, col = 8 * (f & 31);
+      const int rl = CS ? (f >> 4) : (f >> 5), col = CS ? (128 * ch + 8 * (f & 15)) : (8 * (f & 31));
       if (row0 + rl < B) *(bf16x8*)(dH0g + (unsigned)((row0 + rl) * HID + col)) = *(const bf16x8*)(dH0b + rl * H0B_LD + col);
     }
     if (stamped) STAMP(p, 7);
@@ -827,7 +878,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
     //  dH1b writes come behind its own first barrier, its dH0b writes behind its second)
   }
   STAMP(p, 8);
-  if (lb >= n_rt) block_sums();      // (a block without row tiles still owns a slab: zeros)
+  if (rt0 >= n_rt) block_sums();      // (a block without row tiles still owns a slab: zeros)
   STAMP(p, 9);
   RT_STAMP(p, 14, rt_entry_);
   RT_STAMP(p, 15, iql_realtime());

@@ -70,12 +70,17 @@ for i in (0, 1, 4, 6):
 report("fwd all", st[ids[inst != 7]], FWD)
 cpb = int(os.environ.get("IQLHIP_LB_CPB", max(1, min(8, n_chunk // 4))))
 n_cg = (n_chunk + cpb - 1) // cpb
-ids = np.arange(8 * (nbb // 2))
+csplit = even <= 32 and os.environ.get("IQLHIP_LB_CSPLIT", "1") != "0" and "IQLHIP_LB_NBB" not in os.environ
+ids = np.arange(8 * nbb if csplit else 8 * (nbb // 2))      # (column split: two blocks per row tile, half = bit 0 of blockIdx >> 3)
 net = ids & 3
 LR = [(1, "first tile's loads + persistent operand loads issued"), (2, "H1 tile -> LDS, dy / dY (waits for the loads)"), (3, "barrier"), (4, "dH1 tile + barrier"),
       (5, "dH1 store, dH0 reads + 64 MFMAs"), (6, "mask, dH0 tile, next tile's loads + barrier"), (7, "dH0 store"), (8, "rest of the row tiles"), (9, "block sums -> slab")]
 for n, nm in enumerate(("V", "Q1", "Q2", "PI")):
-    report(f"bwd rows {nm}", st[2048 + ids[net == n]], LR)
+    if csplit:
+        for ch in (0, 1):
+            report(f"bwd rows {nm} column half {ch}", st[2048 + ids[(net == n) & (((ids >> 3) & 1) == ch)]], LR)
+    else:
+        report(f"bwd rows {nm}", st[2048 + ids[net == n]], LR)
 report("bwd rows all", st[2048 + ids], LR)
 ng = 8 * ((28 * n_cg + 1) // 2)
 ids = np.arange(ng)
