@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
  f32x4 xv[NKB];
   unsigned xsh[NKB];      // (the last floats of the batch are read from its last 16 bytes: the wanted elements sit xsh places up)
   int x_row = 0;          // the batch row this thread's X values belong to (x_store)
-  auto x_issue = [&](int rt) {
+  auto x_issue = [&](int rt) __attribute__((always_inline)) {
     const unsigned row = (unsigned)min(rt * RT_ROWS + xr, B - 1);
 #pragma unroll
     for (int q = 0; q < NKB; ++q) {
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
       xv[q] = *(const f32x4u*)(xb + idx);      // (ISSUE only: the shift is applied in x_store — used here, every load was waited for on the spot)
     }
   };
-  auto x_store = [&]() {
+  auto x_store = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NKB; ++q) {
       if (q < nkb) {
@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   }
 
   STAMP(p, 1);
+  // (At the head of this loop, whose body re-issues the X prefetch, the compiler assumes those loads are nearly the last in
+  //  flight: the wait in front of x_store() is vmcnt(8), i.e. on the way in from the prologue the first tile's layer 0 starts
+  //  behind the whole W1 image.  Peeling the first tile — exact counts there — was measured: forward 9.36 -> 9.45 us at 1 024
+  //  rows, 37.8 -> 38.8 at 8 192: the second copy of the body costs more than the overlap gives, profiles/r04_ab_lb_peel.txt.)
   for (; rt < n_rt; rt += nbi) {
     const int row0 = rt * RT_ROWS;
     const bool first = (rt == ib + LB_STAMP_TILE * nbi);      // (the tile whose phases the diagnostic build stamps)
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   __bf16* dYb = dH0b + 32 * H0B_LD;                    // [32][LB_DYLD] dY of the tile (policy)
   float* dys = (float*)(dYb + 32 * LB_DYLD);           // [32] dy of the tile (scalar nets)
   const int xr = tid >> 3, xc = tid & 7;
-  auto issue = [&](LbTileIn& s, int rt) {
+  auto issue = [&](LbTileIn& s, int rt) __attribute__((always_inline)) {
     const int row0 = rt * RT_ROWS;
     if (wave == 0) row_issue(p, LBROW(row0 + (tid & 31)), s.in);
     const unsigned prow = (unsigned)LBROW(row0 + xr);
@@ -661,7 +665,8 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   // ---- the block's sums -> its slab (arena layout).  Run in FRONT of the last tile's dH0 copy-out (LDS region of its own):
   // behind it, the first registers it touches were the copy-out stores' sources, and the block waited ~4 k cycles for
   // those stores to complete before it even started — and then once more for its own stores at the end of the kernel.
-  auto block_sums = [&]() {
+  // (the loss sums by value: captured by reference in this closure AND in do_tile's, which calls it, they landed in scratch)
+  auto block_sums = [&](const float accA, const float accB, const float accb2) __attribute__((always_inline)) {
   float* pip = (float*)(dys + 32);     // [2][4 waves][32] policy db2 / dlog_std partials
   float* rsm = pip + 2 * 4 * 32;       // [16]
   if (CS && ch == 1) {      // (block-uniform) the second block of a tile: db1 / the scalar dW2 (the column sums over the dH1 and
@@ -728,7 +733,12 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   };
   STAMP(p, 1);
 
-  for (int rt = rt0; rt < n_rt; rt += rts) {
+  // One row tile.  CS: a block has exactly one, so there is no loop — and without the back edge the compiler counts the
+  // loads in flight exactly (at the head of a loop whose body re-issues the tile inputs it assumes they are the last loads
+  // issued, and the first tile's arithmetic starts behind the whole W1 stream): row kernel 7.74 -> 7.37 us at 1 024 rows.
+  // (Peeling the first tile of the general loop the same way: 9.57 -> 9.37 us at 2 048 rows but 25.15 -> 25.47 at 8 192 — not
+  //  done, profiles/r04_ab_lb_peel.txt.)
+  auto do_tile = [&](const int rt) __attribute__((always_inline)) {
     const int row0 = rt * RT_ROWS;
     const bool first = (rt == rt0);
     const bool stamped = (rt == rt0 + LB_STAMP_TILE * rts);      // (the tile whose phases the diagnostic build stamps)
@@ -739,12 +749,33 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
       *(bf16x8*)(H1t + (f >> 5) * H0B_LD + 8 * (f & 31)) = T.h1q[q];
     }
     // ---- dy of the scalar heads / dY = w T of the policy; the per-row sums
+    // (this tile's contributions to the block's loss sums are collected in locals and added behind the two net kinds'
+    //  branches, in ONE place: with an `acc += ...` at the end of each branch the optimiser sank the updates into the join
+    //  behind a pointer phi — while the accumulators were still closure captures — and they stayed in scratch memory)
+    float tA = 0.f, tB = 0.f, tb2 = 0.f;
     if (!is_pi) {
       if (tid < RT_ROWS) {
+        // (row_finish's arithmetic restated by value: inside this closure its three by-address results landed in scratch)
         float v = 0.f, la_ = 0.f, lb_ = 0.f;
-        if (row0 + tid < B) row_finish(p, net, T.in, &v, la_, lb_);
+        if (row0 + tid < B) {
+          if (net == IQLHIP_NET_V) {
+            const float tq = fminf(sum4(T.in.h[2]), sum4(T.in.h[3]));
+            const float u = tq - sum4(T.in.h[1]);
+            const float wgt = fabsf(p.hy.iql_tau - ((u < 0.f) ? 1.f : 0.f));
+            la_ = wgt * u * u;
+            v = (-2.f * wgt * u) * invB;
+          } else {
+            const float nv = sum4(T.in.h[0]);
+            const float y = T.in.r + ((1.f - T.in.d) * p.hy.discount) * nv;
+            const float e1 = sum4(T.in.h[4]) - y;
+            const float e2 = sum4(T.in.h[5]) - y;
+            la_ = e1 * e1;
+            lb_ = e2 * e2;
+            v = ((net == IQLHIP_NET_Q1) ? e1 : e2) * invB;
+          }
+        }
         dys[tid] = v;
-        if (ch == 0) { accA += la_; accB += lb_; accb2 += v; }
+        tA = la_; tB = lb_; tb2 = v;
       }
     } else {
       float w = 0.f;
@@ -757,12 +788,14 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
       const bf16x4 dyb = cvt4(dy4);
       *(bf16x4*)(dYb + xr * LB_DYLD + 4 * xc) = dyb;
       if (row0 + xr < B && ch == 0) *(bf16x4*)(dyg + (unsigned)((row0 + xr) * 32 + 4 * xc)) = dyb;
-      if (ch == 0) {
-        pb2 += dy4;
-        pls += T.g4 * w;
-        if (xc == 0) accA += w * T.lrow;
-      }
+      const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      pb2 += (ch == 0) ? dy4 : z4;
+      pls += (ch == 0) ? T.g4 * w : z4;
+      tA = (xc == 0) ? w * T.lrow : 0.f;
     }
+    accA += (ch == 0) ? tA : 0.f;
+    accB += (ch == 0) ? tB : 0.f;
+    accb2 += (ch == 0) ? tb2 : 0.f;
     if (stamped) STAMP(p, 2);
     __syncthreads();
     if (stamped) STAMP(p, 3);
@@ -852,13 +885,13 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
         }
     }
     // the next tile's inputs: everything of this tile's has been consumed
-    if (rt + rts < n_rt) issue(T, rt + rts);
+    if (!CS && rt + rts < n_rt) issue(T, rt + rts);      // (CS: one tile per block, nbb >= n_rt)
     __syncthreads();
     if (stamped) STAMP(p, 6);
 #pragma unroll
     for (int t = 0; t < NTB; ++t)      // column sums of the dH0 tile (CS: of the block's half, two 16-column tiles per wave)
       sum0[t] = MFMA_BF16(ones, COLSUM_B(dH0b, CS ? (128 * ch + 32 * wave + 16 * t) : (64 * wave + 16 * t)), sum0[t]);
-    if (rt + rts >= n_rt) block_sums();      // (the block's last tile)
+    if (rt + rts >= n_rt) block_sums(accA, accB, accb2);      // (the block's last tile)
     // dH1 / dH0 rows -> memory (operands of dW1 = dH1^T . H0, dW0 = dH0^T . X): the tile's last instructions — a register
     // that was a store's source is not reused before the store has completed (~4 k cycles)
 #pragma unroll
@@ -876,9 +909,14 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
     if (stamped) STAMP(p, 7);
     // (no barrier here: the next tile's first LDS writes — H1t, dYb / dys — were last read before the barrier above, its
     //  dH1b writes come behind its own first barrier, its dH0b writes behind its second)
+  };
+  if constexpr (CS) {
+    if (rt0 < n_rt) do_tile(rt0);
+  } else {
+    for (int rt = rt0; rt < n_rt; rt += rts) do_tile(rt);
   }
   STAMP(p, 8);
-  if (rt0 >= n_rt) block_sums();      // (a block without row tiles still owns a slab: zeros)
+  if (rt0 >= n_rt) block_sums(accA, accB, accb2);      // (a block without row tiles still owns a slab: zeros)
   STAMP(p, 9);
   RT_STAMP(p, 14, rt_entry_);
   RT_STAMP(p, 15, iql_realtime());
