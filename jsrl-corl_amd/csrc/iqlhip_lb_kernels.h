@@ -739,6 +739,10 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
   // (Peeling the first tile of the general loop the same way: 9.57 -> 9.37 us at 2 048 rows but 25.15 -> 25.47 at 8 192 — not
   //  done, profiles/r04_ab_lb_peel.txt.)
   auto do_tile = [&](const int rt) __attribute__((always_inline)) {
+    // (no implicit fused multiply-adds in the tile's arithmetic: left to -ffp-contract the two instantiations contracted
+    //  `r + c * nv` and `acc += w * l` differently, and one bf16 dH1 value in ~10^5 came out one ulp apart — the column-split
+    //  form must reproduce the one-block form bit for bit, tests/test_hip_lb.py)
+#pragma clang fp contract(off)
     const int row0 = rt * RT_ROWS;
     const bool first = (rt == rt0);
     const bool stamped = (rt == rt0 + LB_STAMP_TILE * rts);      // (the tile whose phases the diagnostic build stamps)

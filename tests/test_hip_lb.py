@@ -113,6 +113,31 @@ def test_lb_bf16_dropout_and_against_small_batch_kernels(monkeypatch):
             assert np.max(np.abs(outs[0][1][n][k] - outs[1][1][n][k])) <= 2.5 * 2 * 3e-4, (n, k)
 
 
+@pytest.mark.parametrize("B", [1024, 600, 1000])
+def test_row_kernel_column_split_is_bit_identical(B, monkeypatch):
+    """Up to 1 024 rows the row kernel spreads a row tile over two blocks (each half of the dH0 columns, one shared slab
+    of sums; IQLHIP_LB_CSPLIT=0 keeps one block per tile): every sum is still formed by one block in the same order, so
+    gradients, losses and the parameters after two steps are bit for bit the same (ragged last tiles and an odd tile count
+    included)."""
+    build, read_params, to_tb, unflat = _hip()
+    S, A = 39, 28
+    params, batch, hyper, lrs = _case(S, A, B, seed=900 + B, gaussian=True)
+    outs = []
+    for cs in ("1", "0"):
+        monkeypatch.setenv("IQLHIP_LB_CSPLIT", cs)
+        tr = build(params, S, A, True, hyper, lrs, 1000)
+        tr.set_precision("bf16")
+        tb = to_tb(batch)
+        flat = tr.flat_gradient(tb).copy()
+        logs = [tr.train(tb) for _ in range(2)]
+        outs.append((flat, logs, read_params(tr)))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    for n in outs[0][2]:
+        for k in outs[0][2][n]:
+            assert np.array_equal(outs[0][2][n][k], outs[1][2][n][k]), (n, k)
+
+
 @pytest.mark.parametrize("K,B", [(6, 256), (5, 1024), (3, 600)])
 def test_bf16_train_steps_graph_matches_eager_steps_on_same_indices(K, B):
     """bf16 precision: K steps through the multi-step driver (chunk graphs, device index draw, rows staged by the forward's
