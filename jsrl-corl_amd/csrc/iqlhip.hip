@@ -165,6 +165,7 @@ struct iqlhip_ctx {
   __bf16* wimg = nullptr;             // bf16 path: operand images of W1 / W0, [6][IMG_STRIDE] (iqlhip_kernels.h)
   int lb_enabled = 1;                 // diagnostic (IQLHIP_LB=0): keep the small-batch kernels at every batch size
   int lb_nbb_force = -1, lb_cpb_force = -1, lb_nbi_force = -1;   // diagnostic (IQLHIP_LB_NBB / _CPB / _NBI)
+  bool lb_pi_spread = true;           // IQLHIP_LB_PI_SPREAD=0: the policy's forward tiles on its own 32 blocks only (diagnostic)
   bool lb_csplit = true;              // IQLHIP_LB_CSPLIT=0: no column split of the row kernel at <= 1 024 rows (diagnostic)
   int lb_bwd_part = 0;                // iqlhip_debug_time_kernel only: 1 = launch the row kernel alone, 2 = the GEMM kernel alone
   size_t lds_bwd_lb = 0;
@@ -347,6 +348,7 @@ static int create_impl(iqlhip_ctx* c, const iqlhip_dims* dims, const iqlhip_hype
   if (const char* ov = getenv("IQLHIP_LB")) c->lb_enabled = atoi(ov) != 0;                                     // diagnostic (tools/)
   if (const char* ov = getenv("IQLHIP_LB_NBB")) c->lb_nbb_force = std::max(2, atoi(ov));
   if (const char* ov = getenv("IQLHIP_LB_CSPLIT")) c->lb_csplit = atoi(ov) != 0;
+  if (const char* ov = getenv("IQLHIP_LB_PI_SPREAD")) c->lb_pi_spread = atoi(ov) != 0;
   if (const char* ov = getenv("IQLHIP_LB_CPB")) c->lb_cpb_force = std::max(1, atoi(ov));
   if (const char* ov = getenv("IQLHIP_LB_NBI")) c->lb_nbi_force = std::max(2, atoi(ov));
   c->lds_fwd = fwd_fixed + (size_t)HID * w0_lds_k * sizeof(float) + (w0_lds_k > W0_LDS_MAX_K ? 4096 : 0);
@@ -767,9 +769,17 @@ static void launch_fwd(const iqlhip_ctx* c, const StepParams& p_in, hipStream_t 
     const LbArgs a = lb_args(c, p.rows);
     const int kq = c->dims.state_dim + c->dims.action_dim;
     const dim3 grid(8 * a.nbi);
-    if (kq <= 32) hipLaunchKernelGGL(iql_fwd_lb_kernel<1>, grid, dim3(256), 0, st, p, a);
-    else if (kq <= 64) hipLaunchKernelGGL(iql_fwd_lb_kernel<2>, grid, dim3(256), 0, st, p, a);
-    else hipLaunchKernelGGL(iql_fwd_lb_kernel<3>, grid, dim3(256), 0, st, p, a);
+    // (the policy's tiles over its own and the idle blocks, iql_fwd_lb_kernel: from 3 tiles per block on the idle block takes 3 / 8 of them)
+    const bool spread = a.n_rt > 2 * a.nbi && c->lb_pi_spread;
+    if (spread) {
+      if (kq <= 32) hipLaunchKernelGGL((iql_fwd_lb_kernel<1, true>), grid, dim3(256), 0, st, p, a);
+      else if (kq <= 64) hipLaunchKernelGGL((iql_fwd_lb_kernel<2, true>), grid, dim3(256), 0, st, p, a);
+      else hipLaunchKernelGGL((iql_fwd_lb_kernel<3, true>), grid, dim3(256), 0, st, p, a);
+    } else {
+      if (kq <= 32) hipLaunchKernelGGL((iql_fwd_lb_kernel<1, false>), grid, dim3(256), 0, st, p, a);
+      else if (kq <= 64) hipLaunchKernelGGL((iql_fwd_lb_kernel<2, false>), grid, dim3(256), 0, st, p, a);
+      else hipLaunchKernelGGL((iql_fwd_lb_kernel<3, false>), grid, dim3(256), 0, st, p, a);
+    }
     return;
   }
   const int n_rt = (p.rows + RT_ROWS - 1) / RT_ROWS;

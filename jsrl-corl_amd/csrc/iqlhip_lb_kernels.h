@@ -127,7 +127,8 @@ __device__ __forceinline__ void iql_w1t_build(const StepParams& p, __bf16* w1t, 
 // Forward.  grid = 8 x nbi; XCD map and instance pairs as iql_fwd_kernel's (XCDs n and n + 4 host the two instances that
 // read net n's weights; block parity = row-tile parity, which the backward's (b) blocks of that parity read back).
 // NKB: 32-wide k-blocks of the widest layer-0 input (S + A <= 128 -> <= 4).
-template <int NKB>
+// SPREAD (more than one row tile per block, i.e. above 1 024 rows): see pi_spread below.
+template <int NKB, bool SPREAD = false>
 __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a) {
   constexpr int XLD = 32 * NKB + 8;       // bf16 row stride of the X tile
   __shared__ __attribute__((aligned(16))) __bf16 Xb[32 * XLD];
@@ -139,16 +140,37 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   const int bid = blockIdx.x;
   const int fx = bid & 7, fh = fx >> 2, fr = bid >> 3;
   constexpr unsigned FWD_PAIR_A = 0x6541u, FWD_PAIR_B = 0x7320u;      // (iql_fwd_kernel)
-  const int inst = (int)((((fr & 1) ? FWD_PAIR_B : FWD_PAIR_A) >> (4 * (fx & 3))) & 7u);
+  int inst = (int)((((fr & 1) ? FWD_PAIR_B : FWD_PAIR_A) >> (4 * (fx & 3))) & 7u);
   const int nbi = a.nbi;
-  const int ib = (fr >> 1) * 2 + fh;
-  if (inst >= 7) {      // the idle eighth: W1 transposed for the backward; in graph chunks the NEXT step's bookkeeping
-    iql_w1t_build(p, a.w1t, H0b, ib, nbi);
-    if (p.g_work) idle_block_work(p.g_work, ib, nbi);
-    return;
-  }
+  int ib = (fr >> 1) * 2 + fh;
   const int n_rt = a.n_rt;
-  if (ib >= n_rt) return;
+  // The policy's blocks are the forward's longest (its loss terms: +2 k cycles per row tile), and they share their XCD pair
+  // with the idle eighth, whose blocks are done after a few microseconds: at 8 192 rows the policy's 32 blocks ended the
+  // launch at 38 us while every other block was done by 31.  SPREAD: of the T = ceil(n_rt / nbi) tiles a policy block would
+  // walk, the idle block of the same index takes the last 3 T / 8 (none below 3 tiles per block: in graph chunks the idle
+  // duties include the next step's gather, ~16 k cycles at 8 192 rows — with an even split the idle blocks became the
+  // launch's last ones instead).  Same stride, same parity, hence the same XCD as the tiles' consumers; the idle duties
+  // (nothing in this launch consumes them) run behind the block's tiles.
+  int rt_hi = n_rt;                      // the block's tiles: ib, ib + nbi, ... below rt_hi
+  const int ib_idle = ib;
+  const bool idle_block = inst >= 7;
+  if constexpr (SPREAD) {
+    const int T = (n_rt + nbi - 1) / nbi;
+    const int t_idle = (3 * T) >> 3;
+    if (idle_block) {
+      inst = 6;
+      ib += nbi * (T - t_idle);          // (>= n_rt when it takes no tiles: the loop below does not run)
+    } else if (inst == 6) {
+      rt_hi = min(n_rt, ib + nbi * (T - t_idle));
+    }
+  } else {
+    if (idle_block) {      // the idle eighth: W1 transposed for the backward; in graph chunks the NEXT step's bookkeeping
+      iql_w1t_build(p, a.w1t, H0b, ib, nbi);
+      if (p.g_work) idle_block_work(p.g_work, ib, nbi);
+      return;
+    }
+    if (ib >= n_rt) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   // Which 64 units a wave owns, in which order it walks their four 16-unit tiles and W1's eight k-blocks, ROTATES with the
@@ -308,7 +330,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
   //  flight: the wait in front of x_store() is vmcnt(8), i.e. on the way in from the prologue the first tile's layer 0 starts
   //  behind the whole W1 image.  Peeling the first tile — exact counts there — was measured: forward 9.36 -> 9.45 us at 1 024
   //  rows, 37.8 -> 38.8 at 8 192: the second copy of the body costs more than the overlap gives, profiles/r04_ab_lb_peel.txt.)
-  for (; rt < n_rt; rt += nbi) {
+  for (; rt < rt_hi; rt += nbi) {
     const int row0 = rt * RT_ROWS;
     const bool first = (rt == ib + LB_STAMP_TILE * nbi);      // (the tile whose phases the diagnostic build stamps)
     // policy: this tile's actions and dropout keep-bits (in flight under layer 0)
@@ -335,7 +357,7 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
     x_store();
     __syncthreads();
     if (first) STAMP(p, 2);
-    if (rt + nbi < n_rt) x_issue(rt + nbi);       // the next tile's rows, under this tile's arithmetic
+    if (rt + nbi < rt_hi) x_issue(rt + nbi);       // the next tile's rows, under this tile's arithmetic
 
     // ---- layer 0: H0[32 rows][units 64 w ..]: A = W0 (m = unit), B = X (n = row)
     {
@@ -514,6 +536,13 @@ __global__ __launch_bounds__(256) void iql_fwd_lb_kernel(StepParams p, LbArgs a)
     if (first) STAMP(p, 8);
   }
   STAMP(p, 9);
+  if constexpr (SPREAD) {
+    if (idle_block) {
+      __syncthreads();      // (every wave has left the last tile's LDS reads: H0b is the transpose's staging area)
+      iql_w1t_build(p, a.w1t, H0b, ib_idle, nbi);
+      if (p.g_work) idle_block_work(p.g_work, ib_idle, nbi);
+    }
+  }
   RT_STAMP(p, 14, rt_entry_);
   RT_STAMP(p, 15, iql_realtime());
 #undef CP

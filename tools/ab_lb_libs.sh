@@ -1,7 +1,7 @@
 #!/bin/bash
 # interleaved A/B of two libraries on the config-5 bf16 workloads
 out=$1; mkdir -p "$(dirname "$out")"; : > "$out"
-for B in 1024 8192 2048; do
+for B in ${SIZES:-1024 8192 2048}; do
   steps=3000; [ $B = 8192 ] && steps=1500
   for i in 1 2 3; do
     for L in jsrl-corl_amd/libiqlhip_base.so jsrl-corl_amd/libiqlhip.so; do
