@@ -138,11 +138,13 @@ def test_row_kernel_column_split_is_bit_identical(B, monkeypatch):
             assert np.array_equal(outs[0][2][n][k], outs[1][2][n][k]), (n, k)
 
 
-@pytest.mark.parametrize("K,B", [(6, 256), (5, 1024), (3, 600)])
+@pytest.mark.parametrize("K,B", [(6, 256), (5, 1024), (3, 600), (3, 4096)])
 def test_bf16_train_steps_graph_matches_eager_steps_on_same_indices(K, B):
     """bf16 precision: K steps through the multi-step driver (chunk graphs, device index draw, rows staged by the forward's
     idle blocks) equal K eager bf16 steps fed with the same indices — bitwise.  256 rows run the small-batch bf16 kernels,
-    600 and 1 024 rows the large-batch ones (whose idle blocks also transpose W1 for the backward)."""
+    600 and 1 024 rows the large-batch ones (whose idle blocks also transpose W1 for the backward; row kernel: two blocks
+    per tile), 4 096 rows the large-batch forward whose idle blocks first walk 3/8 of the policy's row tiles and stage
+    the next step's rows behind them."""
     import iql
     import iqlhip_binding as hb
     build, read_params, _, _ = _hip()
