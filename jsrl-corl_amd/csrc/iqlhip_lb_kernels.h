@@ -833,26 +833,42 @@ __global__ __launch_bounds__(256) void iql_bwd_rows_kernel(StepParams p, LbArgs 
     __syncthreads();
     if (stamped) STAMP(p, 3);
     // ---- dH1 tile [32][256]: (dY . W2) masked by H1 > 0; lane: rows 16 r2 + l15, columns 64 w + 16 jt + 4 g ..
+    // (all eight mask reads first, the two net kinds in loops of their own: with the kind's branch inside the (r2, jt) loop
+    //  every iteration was an LDS round trip of its own — read, wait, multiply, write — 2.7 k cycles for eight of them)
+    {
+      bf16x4 hmk[2][4];
 #pragma unroll
-    for (int r2 = 0; r2 < 2; ++r2) {
-      bf16x8 Bd = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      float dyr = 0.f;
-      if (is_pi) Bd = *(const bf16x8*)(dYb + (16 * r2 + l15) * LB_DYLD + 8 * g);
-      else dyr = dys[16 * r2 + l15];
+      for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        f32x4 pre;
-        if (is_pi) pre = MFMA_BF16(w2A[jt], Bd, ((f32x4){0.f, 0.f, 0.f, 0.f}));
-        else pre = w2q[jt] * dyr;
-        const bf16x4 hmk = *(const bf16x4*)(H1t + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g);
-        f32x4 o;
+        for (int jt = 0; jt < 4; ++jt) hmk[r2][jt] = *(const bf16x4*)(H1t + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g);
+      f32x4 pre[2][4];
+      if (is_pi) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float h = (float)hmk[reg];
-          o[reg] = (h > 0.f) ? pre[reg] * dscale : 0.f;
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const bf16x8 Bd = *(const bf16x8*)(dYb + (16 * r2 + l15) * LB_DYLD + 8 * g);
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) pre[r2][jt] = MFMA_BF16(w2A[jt], Bd, ((f32x4){0.f, 0.f, 0.f, 0.f}));
         }
-        *(bf16x4*)(dH1b + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g) = cvt4(o);
+      } else {
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const float dyr = dys[16 * r2 + l15];
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) pre[r2][jt] = w2q[jt] * dyr;
+        }
       }
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          f32x4 o;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const float h = (float)hmk[r2][jt][reg];
+            o[reg] = (h > 0.f) ? pre[r2][jt][reg] * dscale : 0.f;
+          }
+          *(bf16x4*)(dH1b + (16 * r2 + l15) * H0B_LD + 64 * wave + 16 * jt + 4 * g) = cvt4(o);
+        }
     }
     __syncthreads();
     if (stamped) STAMP(p, 4);
