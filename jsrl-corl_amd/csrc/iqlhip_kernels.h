@@ -1284,12 +1284,18 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
 #define AROW(ks) (64 * wave + 16 * ((ks) >> 2) + 4 * g + ((ks) & 3))
     typename Frag2<BF16>::type hh[16];
     typename Frag4<BF16>::type bb[16];
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const unsigned row = (unsigned)BROW(cbase + AROW(ks));
-      hh[ks] = ld2<BF16>(H1g, row * (unsigned)HID + (unsigned)(j0 + 2 * l15));
-      bb[ks] = ld4<BF16>(H0g, row * (unsigned)HID + (unsigned)(i0 + 4 * l15));
+    // The 96 KB of activation tiles are requested in four groups with the chunk's loss arithmetic BETWEEN them: a wave spends
+    // ~4 k cycles just issuing its ~60 loads (the four waves share the CU's one vector-memory pipe, ~64 cycles per 1 KB
+    // instruction) with the vector ALU idle, and the per-row inputs requested first are back after the first third of that —
+    // the policy's 2.7 k cycles of advantage weights and (row, dim) terms, which made its blocks the kernel's last, now run
+    // inside the issue phase instead of behind it.  (Scheduling barriers: hipcc otherwise gathers all loads in front again.)
+#define HB_LOAD(k0_, k1_)                                                                               \
+    _Pragma("unroll") for (int ks = (k0_); ks < (k1_); ++ks) {                                          \
+      const unsigned row = (unsigned)BROW(cbase + AROW(ks));                                            \
+      hh[ks] = ld2<BF16>(H1g, row * (unsigned)HID + (unsigned)(j0 + 2 * l15));                          \
+      bb[ks] = ld4<BF16>(H0g, row * (unsigned)HID + (unsigned)(i0 + 4 * l15));                          \
     }
+    HB_LOAD(0, 4);
     PIN_REST();
     float* slab = p.sc.slab_a + (long long)c * p.n_params;
     // dropout: the saved activations are post-dropout, so (h > 0) already encodes relu AND keep; the chain
@@ -1320,18 +1326,28 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
         }
         STAMP(p, 5);
         wS[tid] = wrow;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      HB_LOAD(4, 8);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool gauss = (h_pol == IQLHIP_POLICY_GAUSSIAN);
+      const bool want_dls = designated && gauss;
+      float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (is_pi) {
         __syncthreads();                       // (net is block-uniform)
         STAMP(p, 6);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) wv[cc] = wS[r8 + 32 * cc];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      HB_LOAD(8, 12);
+      __builtin_amdgcn_sched_barrier(0);
+      if (is_pi) {
         // phase 2 (thread = (row, dim)): mean, log-prob term, dL/dpre and dL/dlog_std of every (row, dim) — eight
         // rows of one dim per thread and group of 8 dims, as straight-line select code (pi_items8): written with
         // per-item branches this phase was ~110 LDS / branch round trips (3.3 k cycles, the policy blocks' long pole)
-        const bool gauss = (h_pol == IQLHIP_POLICY_GAUSSIAN);
-        const bool want_dls = designated && gauss;
         const int A = h_A;
         const float invB = p.inv_batch;
-        float wv[8];
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) wv[cc] = wS[r8 + 32 * cc];
         const int DpZ = (D <= 8) ? 8 : Dp;      // dims the dH1 / dW2 products read as operands (zero-filled beyond A)
         for (int e = 0; 8 * e < DpZ; ++e) {
           const int dd = sub + 8 * e;
@@ -1365,6 +1381,10 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
         }
         STAMP(p, 7);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      HB_LOAD(12, 16);
+      __builtin_amdgcn_sched_barrier(0);
+#undef HB_LOAD
       STAMP(p, 11);
       if (loss_block) {
         const float sA = block_sum_256(lossA, rsm);
@@ -1704,13 +1724,17 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
       for (int j = 0; j < 8; ++j) w2v8[j] = *(const f32x4*)(w2 + min(j, D - 1) * HID + 4 * j4);
     }
     // H1 tile [32][256] as float4 f = tid + 256q: row f>>6, cols 4*(f&63)
+    // (the first half of the tile here, the second half and the H0 mask BEHIND the loss arithmetic below: the wave is busy
+    //  issuing loads for ~2 k cycles — the CU's one vector-memory pipe — while the per-row inputs requested first are back
+    //  after half of that; the policy's (row, dim) terms then run inside the issue phase, cf. the dW1 blocks)
     typename Frag4<BF16>::type h1v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int f = tid + 256 * q;
-      const unsigned row = (unsigned)BROW(row0 + (f >> 6));   // rows >= B: dY = 0 -> dH1 = 0
-      h1v[q] = ld4<BF16>(H1g, row * (unsigned)HID + (unsigned)(4 * (f & 63)));
+#define H1V_LOAD(q0_, q1_)                                                                              \
+    _Pragma("unroll") for (int q = (q0_); q < (q1_); ++q) {                                             \
+      const int f = tid + 256 * q;                                                                      \
+      const unsigned row = (unsigned)BROW(row0 + (f >> 6));   /* rows >= B: dY = 0 -> dH1 = 0 */        \
+      h1v[q] = ld4<BF16>(H1g, row * (unsigned)HID + (unsigned)(4 * (f & 63)));                          \
     }
+    H1V_LOAD(0, 4);
     // W1 fragments: k = j in [64*wave, +64), n = i0 + 4*l15 + t — requested after the dY barrier (below): 16 KiB
     // per wave of fragment-shaped loads take ~1.5 k cycles of the CU's vector-memory pipe to issue, which in front of
     // the loss arithmetic only delayed it; issued there they stream in under the dH1 tile phase
@@ -1721,12 +1745,6 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
     typename Frag4<BF16>::type bw[FULLB ? 64 : 16];      // (bf16 path: np.w1 addresses the bf16 shadow of W1)
     // H0 mask slice [32][64] as float4 f = tid + 256q: row f>>4, cols i0 + 4*(f&15)
     typename Frag4<BF16>::type h0v[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int f = tid + 256 * q;
-      const unsigned row = (unsigned)BROW(row0 + (f >> 4));
-      h0v[q] = ld4<BF16>(H0g, row * (unsigned)HID + (unsigned)(i0 + 4 * (f & 15)));
-    }
     const int n_x = RT_ROWS * ld / 4;
     const int x_last = B * ld / 4 - 1;
     PIN_REST();
@@ -1762,6 +1780,16 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
       for (int dd = 0; dd < Dp; ++dd) dyrow[dd] = 0.f;
       if (row < B) row_finish(p, net, in, dyrow, la, lbv);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    H1V_LOAD(4, 8);
+#undef H1V_LOAD
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int f = tid + 256 * q;
+      const unsigned row = (unsigned)BROW(row0 + (f >> 4));
+      h0v[q] = ld4<BF16>(H0g, row * (unsigned)HID + (unsigned)(i0 + 4 * (f & 15)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     STAMP(p, 5);
     // (requested two at a time between the row groups of the dH1 tile below: the four waves' 64 KB take ~1 k cycles of
@@ -1827,22 +1855,42 @@ __global__ __launch_bounds__(256) void iql_bwd_kernel(const float* q_heads, cons
         }
       }
     } else {
+      // (the dY reads of the whole tile in one batch per net kind, then the arithmetic: with the kind's branch inside the row
+      //  loop every row group was an LDS round trip of its own — read, wait, multiply, write)
+      f32x4 sq[8];
+      if (D == 1) {
+        float dy1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dy1[q] = dYs[((tid + 256 * q) >> 6) * DYLD];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sq[q] = dy1[q] * w2v;
+      } else {
+        // dYs is zero-filled up to Dp >= 8 and w2v8[j >= D] repeats row D-1: unconditional float4 LDS reads, four row groups
+        // at a time (registers)
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          f32x4 ya[4], yb[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int rl = (tid + 256 * (4 * hq + qq)) >> 6;
+            ya[qq] = *(const f32x4*)(dYs + rl * DYLD);
+            yb[qq] = *(const f32x4*)(dYs + rl * DYLD + 4);
+          }
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            f32x4 s = ya[qq][0] * w2v8[0];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) s += ya[qq][j] * w2v8[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += yb[qq][j] * w2v8[4 + j];
+            sq[4 * hq + qq] = s;
+          }
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int rl = (tid + 256 * q) >> 6;
-        f32x4 s;
-        if (D == 1) {
-          s = dYs[rl * DYLD] * w2v;
-        } else {
-          // dYs is zero-filled up to Dp >= 8 and w2v8[j >= D] repeats row D-1: unconditional float4 LDS reads in one
-          // batch (a per-dim `if` makes each read -> wait -> fma a serial ~160-cycle step)
-          const f32x4 ya = *(const f32x4*)(dYs + rl * DYLD), yb = *(const f32x4*)(dYs + rl * DYLD + 4);
-          s = ya[0] * w2v8[0];
-#pragma unroll
-          for (int j = 1; j < 4; ++j) s += ya[j] * w2v8[j];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) s += yb[j] * w2v8[4 + j];
-        }
+        const f32x4 s = sq[q];
         f32x4 out;
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = ((float)h1v[q][e] > 0.f) ? s[e] * dscale : 0.f;
