@@ -868,8 +868,12 @@ static void launch_upd(const iqlhip_ctx* c, UpdParams u, hipStream_t st) {
   }
   const int nb = 8 * (int)((seg_max + 2047) / 2048);
   const bool peer = u.n_peer > 0;
-#define UPD_LAUNCH(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P>), dim3(nb), dim3(256), 0, st, u)
-#define UPD_LAUNCH_LB(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P, true>), dim3(nb), dim3(256), 0, st, u)
+  // the leading arguments are preloaded into SGPRs with each wave (iql_update_kernel)
+  const unsigned q_s0 = (unsigned)c->L.net[0].seg_begin, q_s1 = (unsigned)c->L.net[1].seg_begin, q_s2 = (unsigned)c->L.net[2].seg_begin,
+                 q_s3 = (unsigned)c->L.net[3].seg_begin, q_end = (unsigned)c->L.net[3].seg_end;
+  const unsigned q_flags = (!peer && !u.flat_grads && !u.slab_x && u.n_chunk == 1) ? UPD_EARLY_G : 0u;
+#define UPD_LAUNCH(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P>), dim3(nb), dim3(256), 0, st, u.params, u.m, u.v, u.slab_a, q_s0, q_s1, q_s2, q_s3, q_end, q_flags, u)
+#define UPD_LAUNCH_LB(T, P) hipLaunchKernelGGL((iql_update_kernel<T, P, true>), dim3(nb), dim3(256), 0, st, u.params, u.m, u.v, u.slab_a, q_s0, q_s1, q_s2, q_s3, q_end, q_flags, u)
   if (u.slab_x) {      // large-batch bf16 step: the LB instantiations (gradient from the chunk-group slabs unless an exchange
                        // delivered it flat; the operand images of W0 / W1 written next to the bf16 shadows)
     if (u.sched) { if (peer) UPD_LAUNCH_LB(true, true); else UPD_LAUNCH_LB(true, false); }

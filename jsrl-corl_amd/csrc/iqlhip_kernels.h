@@ -2576,22 +2576,16 @@ __global__ __launch_bounds__(256) void iql_grad_flatten_kernel(UpdParams u, floa
 // arguments are frozen, the table is not); otherwise from the kernel argument u.sc.  Two instantiations
 // rather than a run-time pointer select, which would turn every access into a flat load.
 // PEER: the direct-read exchange variant (gradient = rank-ordered sum over UpdParams::peer_flat).
+// Leading arguments (14 dwords, PRELOADED into SGPRs with the wave, cf. iql_bwd_kernel): the three state arenas, the chunk
+// slab, the four segment starts and the end of the last segment as 32-bit element offsets, and q_flags: bit 0 = "the W1
+// gradient of an element is the single word slab_a[e]" (one chunk slab, no exchange, not the large-batch form).  A block
+// issues its m / v / p loads — and, for the 91 % of the elements that are W1, the gradient load — ~40 cycles after it starts
+// instead of behind the ~600-cycle fetch of the by-value UpdParams, which now runs under those loads' latency.
+#define UPD_EARLY_G 1u
 template <bool FROM_TABLE, bool PEER, bool LB = false>
-__global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
-  // every kernel-argument word the optimizer path uses, fetched in ONE batch of scalar loads (hipcc otherwise sinks
-  // each load next to its first use: five dependent scalar-cache misses in front of the gradient loads).  ONE asm
-  // statement for all of them: a volatile asm per word is ordered against the others and gets its own wait.
-#define U64(x) ((unsigned long long)(x))
-  asm volatile("" ::"s"(U64(u.L.net[0].seg_begin)), "s"(U64(u.L.net[1].seg_begin)), "s"(U64(u.L.net[2].seg_begin)),
-               "s"(U64(u.L.net[3].seg_begin)), "s"(U64(u.L.net[0].w0)), "s"(U64(u.L.net[1].w0)), "s"(U64(u.L.net[2].w0)),
-               "s"(U64(u.L.net[3].w0)), "s"(U64(u.L.net[0].b0)), "s"(U64(u.L.net[1].b0)), "s"(U64(u.L.net[2].b0)),
-               "s"(U64(u.L.net[3].b0)), "s"(u.L.net[0].k_in), "s"(u.L.net[1].k_in), "s"(u.L.net[2].k_in),
-               "s"(u.L.net[3].k_in), "s"(U64(u.slab_b_off[0])), "s"(U64(u.slab_b_off[1])), "s"(U64(u.slab_b_off[2])),
-               "s"(U64(u.slab_b_off[3])), "s"(U64(u.L.n_params)), "s"(U64(u.L.target_src)), "s"(U64((uintptr_t)u.params)),
-               "s"(U64((uintptr_t)u.target)), "s"(U64((uintptr_t)u.m)), "s"(U64((uintptr_t)u.v)),
-               "s"(U64((uintptr_t)u.slab_a)), "s"(U64((uintptr_t)u.slab_b)), "s"(U64((uintptr_t)u.flat_grads)),
-               "s"(U64((uintptr_t)u.sched)));
-#undef U64
+__global__ __launch_bounds__(256) void iql_update_kernel(float* q_p, float* q_m, float* q_v, const float* q_slab_a, unsigned q_s0,
+                                                         unsigned q_s1, unsigned q_s2, unsigned q_s3, unsigned q_end,
+                                                         unsigned q_flags, UpdParams u) {
   // XCD-affine element map: block (x = blockIdx & 7, q = blockIdx >> 3) — XCD x under the round-robin workgroup
   // dispatch — owns net x & 3, and of that net's arena segment the 64-float stripes of parity x >> 2: window q of 2 048
   // floats, 16 stripes of 16 threads.  The backward's blocks of net n run on XCDs n and n + 4 and a dW1 tile of column
@@ -2600,19 +2594,40 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
   // the stripes their own XCD wrote, and the optimizer state is only ever touched by one XCD.
   const int ux = (int)(blockIdx.x & 7u), uq = (int)(blockIdx.x >> 3);
   const int net = ux & 3, uhalf = ux >> 2;
-  const long long seg_b = (net == 0) ? u.L.net[0].seg_begin : ((net == 1) ? u.L.net[1].seg_begin : ((net == 2) ? u.L.net[2].seg_begin : u.L.net[3].seg_begin));
-  const long long seg_e = (net == 0) ? u.L.net[0].seg_end : ((net == 1) ? u.L.net[1].seg_end : ((net == 2) ? u.L.net[2].seg_end : u.L.net[3].seg_end));
+  // (segments are contiguous and 64-aligned: a net's segment ends where the next one begins, iqlhip_arena_layout)
+  const long long seg_b = (long long)((net == 0) ? q_s0 : ((net == 1) ? q_s1 : ((net == 2) ? q_s2 : q_s3)));
+  const long long seg_e = (long long)((net == 0) ? q_s1 : ((net == 1) ? q_s2 : ((net == 2) ? q_s3 : q_end)));
   const long long e = seg_b + (long long)uq * 2048 + (long long)((((int)threadIdx.x >> 4) * 2 + uhalf) * 64 + ((int)threadIdx.x & 15) * 4);
   if (e < seg_e) {
-    // issue the state loads before the gradient sum so that all of them are in flight together
-    f32x4 m = *(f32x4*)(u.m + e);
-    f32x4 v = *(f32x4*)(u.v + e);
-    f32x4 pw = *(f32x4*)(u.params + e);
+    // issue the state loads before the gradient sum so that all of them are in flight together — from the preloaded
+    // arguments: nothing here waits for `u`
+    f32x4 m = *(f32x4*)(q_m + e);
+    f32x4 v = *(f32x4*)(q_v + e);
+    f32x4 pw = *(f32x4*)(q_p + e);
+    // W1 leads a segment (65 536 elements = 32 of the blocks' 2 048-float windows: the test is block-uniform)
+    const bool early_g = !PEER && !LB && (q_flags & UPD_EARLY_G) != 0u && (e - seg_b) < 65536;
+    f32x4 gr = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (early_g) gr = *(const f32x4*)(q_slab_a + e);
+    __builtin_amdgcn_sched_barrier(0);      // (the loads above are issued BEFORE the argument fetch below is waited for)
+    // every kernel-argument word the optimizer path uses, fetched in ONE batch of scalar loads (hipcc otherwise sinks
+    // each load next to its first use: five dependent scalar-cache misses in front of the gradient loads).  ONE asm
+    // statement for all of them: a volatile asm per word is ordered against the others and gets its own wait.
+#define U64(x) ((unsigned long long)(x))
+    asm volatile("" ::"s"(U64(u.L.net[0].seg_begin)), "s"(U64(u.L.net[1].seg_begin)), "s"(U64(u.L.net[2].seg_begin)),
+                 "s"(U64(u.L.net[3].seg_begin)), "s"(U64(u.L.net[0].w0)), "s"(U64(u.L.net[1].w0)), "s"(U64(u.L.net[2].w0)),
+                 "s"(U64(u.L.net[3].w0)), "s"(U64(u.L.net[0].b0)), "s"(U64(u.L.net[1].b0)), "s"(U64(u.L.net[2].b0)),
+                 "s"(U64(u.L.net[3].b0)), "s"(u.L.net[0].k_in), "s"(u.L.net[1].k_in), "s"(u.L.net[2].k_in),
+                 "s"(u.L.net[3].k_in), "s"(U64(u.slab_b_off[0])), "s"(U64(u.slab_b_off[1])), "s"(U64(u.slab_b_off[2])),
+                 "s"(U64(u.slab_b_off[3])), "s"(U64(u.L.n_params)), "s"(U64(u.L.target_src)), "s"(U64((uintptr_t)u.params)),
+                 "s"(U64((uintptr_t)u.target)), "s"(U64((uintptr_t)u.m)), "s"(U64((uintptr_t)u.v)),
+                 "s"(U64((uintptr_t)u.slab_a)), "s"(U64((uintptr_t)u.slab_b)), "s"(U64((uintptr_t)u.flat_grads)),
+                 "s"(U64((uintptr_t)u.sched)));
+#undef U64
+
     const bool is_q = (net == IQLHIP_NET_Q1 || net == IQLHIP_NET_Q2);
     float* tp = u.target + (is_q ? (e - u.L.target_src) : 0);
     f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (is_q) t = *(f32x4*)tp;
-    f32x4 gr;
     if (PEER) {
       // all ranks' contributions requested together (one fabric round trip), summed in rank order
       static_assert(IQLHIP_MAX_WORLD == 8, "load16_sys_x8");
@@ -2645,7 +2660,7 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
         for (int r = 1; r < IQLHIP_MAX_WORLD; ++r) if (r < u.n_peer) gr += pv[r];
       }
     } else if (u.flat_grads) gr = *(const f32x4*)(u.flat_grads + e);
-    else gr = slab_grad<LB>(u, e, net);
+    else if (!early_g) gr = slab_grad<LB>(u, e, net);
     const int grp = (net == IQLHIP_NET_V) ? 0 : ((net == IQLHIP_NET_PI) ? 2 : 1);
     // (copy by value: a pointer that may address either the kernarg segment or global memory would make
     //  every access a flat load)
@@ -2666,9 +2681,9 @@ __global__ __launch_bounds__(256) void iql_update_kernel(UpdParams u) {
       const float denom = sqrtf(v[k]) / bc2 + eps;
       pw[k] = fmaf(step, m[k] / denom, pw[k]);
     }
-    *(f32x4*)(u.m + e) = m;
-    *(f32x4*)(u.v + e) = v;
-    *(f32x4*)(u.params + e) = pw;
+    *(f32x4*)(q_m + e) = m;
+    *(f32x4*)(q_v + e) = v;
+    *(f32x4*)(q_p + e) = pw;
     if (u.wsh) st4<true>((float*)u.wsh, (unsigned)e, pw);
     if (is_q) {
 #pragma unroll
