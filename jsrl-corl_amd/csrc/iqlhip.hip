@@ -146,6 +146,8 @@ struct iqlhip_ctx {
   unsigned long long sched_want[4] = {0, 0, 0, 0};
   unsigned long long call_seq = 0;
   unsigned* setup_arrivals = nullptr;           // device: block counter of iql_call_setup_kernel
+  char* prep_save = nullptr;                    // device: prepare's copy of the four arenas, kept (a hipFree at the end of prepare
+                                                //   idles the GPU right in front of the caller's first steps)
   hipStream_t sched_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // (the stream a slot's reader was queued on)
   int sched_slot = 0;
   unsigned long long* hdr = nullptr;  // [HDR_WORDS] per-launch values of a chunk (ChunkHdr)
@@ -440,6 +442,7 @@ extern "C" int iqlhip_destroy(iqlhip_ctx* c) {
   if (c->loss_ring) (void)hipHostFree(c->loss_ring);
   if (c->xstatus_host) (void)hipHostFree(c->xstatus_host);
   if (c->setup_arrivals) (void)hipFree(c->setup_arrivals);
+  if (c->prep_save) (void)hipFree(c->prep_save);
   if (c->losses_host) (void)hipHostFree(c->losses_host);
   if (c->on_row_pin) (void)hipHostFree(c->on_row_pin);
   if (c->on_idx_pin) (void)hipHostFree(c->on_idx_pin);
@@ -1700,8 +1703,8 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
   // and restored after it; it reads row 0 only (size = 1); scratch, loss words and ring are transient anyway.  Under
   // data parallelism the rehearsal runs the exchange too — every rank must call prepare (the same number of times).
   const size_t np_b = (size_t)c->L.n_params * sizeof(float), nt_b = (size_t)c->L.n_target * sizeof(float);
-  char* save = nullptr;
-  HIPCHK(hipMalloc((void**)&save, 3 * np_b + nt_b));
+  if (!c->prep_save) HIPCHK(hipMalloc((void**)&c->prep_save, 3 * np_b + nt_b));     // (arena sizes are fixed per context)
+  char* const save = c->prep_save;
   auto copy_all = [&](bool restore) -> hipError_t {
     float* arenas[4] = {c->params, c->m, c->v, c->target};
     size_t off = 0;
@@ -1715,11 +1718,11 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
     return hipSuccess;
   };
   hipError_t e = copy_all(false);
-  if (e != hipSuccess) { (void)hipFree(save); return fail(IQLHIP_EHIP, "prepare: save arenas: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) return fail(IQLHIP_EHIP, "prepare: save arenas: %s", hipGetErrorString(e));
   refresh_shadows(c, cs);
   int slot = 0;
   rc = acquire_sched_slot(c, &slot);
-  if (rc) { (void)hipFree(save); return rc; }
+  if (rc) return rc;
   const unsigned long long drop_step0 = c->drop_step;
   do {
     iqlhip_step_scalars benign;
@@ -1773,7 +1776,6 @@ extern "C" int iqlhip_train_steps_prepare(iqlhip_ctx* c, const float* rows_dev, 
   e = copy_all(true);
   refresh_shadows(c, cs);
   hipError_t e2 = hipStreamSynchronize(cs);
-  (void)hipFree(save);
   if (rc) return rc;
   if (e != hipSuccess || e2 != hipSuccess) return fail(IQLHIP_EHIP, "prepare: restore arenas: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   return IQLHIP_OK;
